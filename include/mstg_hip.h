@@ -1,0 +1,133 @@
+/*
+ * mstg_hip.h -- C ABI of the MI355X (gfx950) hot-path library for multi-style-transfer-gan.
+ *
+ * The reference has no FFI / operator boundary of its own: its hot path is torch.nn layers called from
+ * enhanced_generator.py.  This header is the boundary the reference would bind instead of
+ * those layers; every entry point names the reference call site it replaces.  Conventions:
+ *
+ *   - plain C, device pointers + explicit sizes + a hipStream_t passed as void*; no torch types;
+ *   - every function returns 0 on success or a negative MSTG_E_* code (the Python shim raises RuntimeError);
+ *   - the caller owns every buffer, workspaces included (sizes from the *_workspace_bytes queries);
+ *   - the library keeps no mutable global state; calls are asynchronous on `stream`;
+ *   - activations are fp32 NHWC ("channels last") unless a descriptor flag says NCHW (only the 3-channel
+ *     image tensors at the module boundary are NCHW); weights stay in PyTorch's own layouts
+ *     (Conv2d OIHW, ConvTranspose2d IOHW) so reference state_dicts are consumed as they are.
+ */
+#ifndef MSTG_HIP_H
+#define MSTG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSTG_OK 0
+#define MSTG_E_BADARG (-1)      /* inconsistent sizes / unsupported geometry */
+#define MSTG_E_ALIGN (-2)       /* channel counts / offsets violate the alignment the kernels need */
+#define MSTG_E_LAUNCH (-3)      /* hipLaunch failed; see mstg_last_error() */
+#define MSTG_E_WORKSPACE (-4)   /* workspace too small */
+#define MSTG_E_UNSUPPORTED (-5) /* valid request outside what this build implements */
+
+/* activation codes shared by conv epilogues and the norm kernels */
+#define MSTG_ACT_NONE 0
+#define MSTG_ACT_RELU 1
+#define MSTG_ACT_LEAKY02 2 /* LeakyReLU(0.2), enhanced_generator.py:238-251, pretrain.py:67-76 */
+#define MSTG_ACT_TANH 3    /* nn.Tanh, enhanced_generator.py:138 */
+
+const char* mstg_version(void);    /* "mstg-hip <semver> gfx950" */
+const char* mstg_arch(void);       /* "gfx950" */
+const char* mstg_last_error(void); /* text of the last failing HIP call on this thread, "" if none */
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolutions.  One descriptor describes the MODULE (nn.Conv2d or nn.ConvTranspose2d); the three
+ * entry points are its forward, its input gradient and its weight/bias gradient.
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d at enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,
+ * 237-265 and pretrain.py:65-91 (their ATen convolution / convolution_backward dispatch).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mstg_conv_desc {
+    int32_t N, H, W, Cin;   /* module input  (N,H,W,Cin)  */
+    int32_t Ho, Wo, Cout;   /* module output (N,Ho,Wo,Cout) */
+    int32_t KH, KW, stride, pad, dil;
+    int32_t transposed;     /* 0: Conv2d (weight OIHW); 1: ConvTranspose2d k4 s2 p1 (weight IOHW) */
+    int32_t x_nchw, y_nchw; /* 1: that tensor is NCHW (3-channel image boundary), else NHWC */
+    int32_t x_ctot, x_coff; /* module input  = channels [x_coff, x_coff+Cin)  of an NHWC tensor with x_ctot channels */
+    int32_t y_ctot, y_coff; /* module output = channels [y_coff, y_coff+Cout) of an NHWC tensor with y_ctot channels */
+    int32_t act;            /* forward epilogue activation applied after bias: MSTG_ACT_NONE or MSTG_ACT_TANH */
+    int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
+} mstg_conv_desc;
+
+int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias /*nullable*/,
+                    float* y, void* stream);
+/* dx = d(loss)/d(module input), from dy = d(loss)/d(module output) */
+int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* stream);
+/* dw (same layout as w) and dbias (nullable) ; workspace holds per-split partial sums (deterministic, no atomics) */
+size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d);
+int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False, eps=1e-5, biased variance) fused with the activation that follows it and an
+ * optional residual add.  Replaces nn.InstanceNorm2d + nn.ReLU / nn.LeakyReLU(0.2) pairs at
+ * enhanced_generator.py:54-75,93-94,100-101,107-108,122-123,129-130,242-251,263-264 and the `+ x` of :84.
+ *   y = act((x - mean) * rstd) [+ residual]      stats[n][c] = {mean, rstd} is saved for the backward.
+ * batch_stats=1 turns it into BatchNorm2d (training: statistics over N,H,W; pretrain.py:69-89) with affine
+ * gamma/beta and running-stat update (momentum 0.1, unbiased running_var); batch_stats=2 = BatchNorm eval.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mstg_norm_workspace_bytes(int N, int HW, int C);
+int mstg_norm_act_fwd(const float* x, const float* residual /*nullable*/, float* y, float* stats /* [N][C][2] */,
+                      int N, int HW, int C, int act, int batch_stats, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, void* workspace, size_t workspace_bytes, void* stream);
+/* dx from dy (gradient w.r.t. y); the residual's gradient is dy itself.  dgamma/dbeta only for batch_stats=1. */
+int mstg_norm_act_bwd(const float* x, const float* stats, const float* dy, float* dx, int N, int HW, int C, int act,
+                      int batch_stats, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LocalAttention core (enhanced_generator.py:22-35,39-42), window 4x4.  The qkv and proj 1x1 convolutions
+ * (:28, :36) run through mstg_conv2d_*; this is everything between them, per window, with the reference's
+ * window partition / un-partition permutes reduced to index arithmetic on NHWC:
+ *   q,k L2-normalised per pixel over channels (F.normalize, eps 1e-12) ; attn = softmax_c2(sum_p q^[p,c1] k^[p,c2])
+ *   (C x C per window, no scale) ; o[p,c1] = sum_c2 attn[c1,c2] v[p,c2].
+ * qkv: NHWC (N,H,W,3C) with q|k|v channel blocks (= qkv.chunk(3, dim=1)); o: NHWC (N,H,W,C).
+ * H, W multiples of 4 (anything else raises in the reference too); C a multiple of 4, <= 64 in this build.
+ * ---------------------------------------------------------------------------------------------- */
+int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int H, int W, int C, void* stream);
+/* dqkv from d_o; the attention matrix is recomputed from qkv, nothing but qkv is saved by the forward */
+int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise / reduction helpers of the training step (enhanced_train.py:49-52,72-115,36-43).
+ * ---------------------------------------------------------------------------------------------- */
+/* y = act(x) ; dx = dy * act'(x)  (LeakyReLU(0.2) of the discriminator stem; Tanh backward uses y) */
+int mstg_act_fwd(const float* x, float* y, size_t n, int act, void* stream);
+int mstg_act_bwd(const float* x_or_y, const float* dy, float* dx, size_t n, int act, void* stream);
+/* mean losses: out[0] = mean(|a-b|) (kind 0, nn.L1Loss) or mean((a-b)^2) (kind 1, nn.MSELoss);
+ * b == NULL means the constant `bconst`.  Deterministic two-stage reduction; workspace >= 4 KiB + 8 B per 4096 elems */
+size_t mstg_loss_workspace_bytes(size_t n);
+int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, size_t n, int kind, float* out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* da = gscale[0]*scale * d(mean loss)/da ; db (nullable) = -da */
+int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, size_t n, int kind, const float* gscale, float scale,
+                       float* da, float* db, void* stream);
+/* per-channel sum over pixels of an NHWC tensor slice: out[c] = sum_p x[p][coff+c]  (bias gradients, pooling) */
+size_t mstg_channel_sum_workspace_bytes(size_t P, int C);
+int mstg_channel_sum(const float* x, size_t P, int ctot, int coff, int C, float scale, float* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* same for a planar NCHW tensor (the 3-channel image tensors): out[c] = scale * sum_{n,i} x[n][c][i] */
+size_t mstg_plane_sum_workspace_bytes(int N, int C, size_t HW);
+int mstg_plane_sum(const float* x, int N, int C, size_t HW, float scale, float* out, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* nn.AdaptiveAvgPool2d(1) on NHWC (enhanced_generator.py:143,257): x (S,P,C) -> out (S,C) = mean over P; and its
+ * gradient dx[s][p][c] = dy[s][c] / P */
+int mstg_segment_mean_fwd(const float* x, int S, size_t P, int C, float* out, void* stream);
+int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, float* dx, void* stream);
+/* torch.optim.Adam step over one flat fp32 buffer (enhanced_train.py:36-43: betas (0.5,0.999), eps 1e-8) */
+int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                        float eps, int step, const unsigned char* mask /*nullable: 0 = skip element*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSTG_HIP_H */

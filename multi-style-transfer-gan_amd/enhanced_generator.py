@@ -1,0 +1,203 @@
+"""Drop-in for the reference's ``enhanced_generator`` module, running on hand-written MI355X (gfx950) kernels.
+
+Put this directory on ``PYTHONPATH`` and the reference's callers (``advanced_transform.py:8``,
+``batch_process_images.py:18``, ``direct_transform.py``, ``enhanced_train.py:10`` ...) import these classes instead
+of the torch.nn originals: same class names, constructor signatures, ``forward`` contracts (NCHW fp32 in/out),
+``gradient_checkpointing_enable()`` and state_dict keys/shapes, so reference ``.pth``
+files load unchanged.
+
+What is different is everything below ``forward``: activations stay NHWC between ops, InstanceNorm+ReLU(+residual)
+is one fused kernel pair, the four MultiScaleBlock branches write straight into the concatenated buffer, the
+window partition/un-partition permutes of LocalAttention are index arithmetic inside the attention kernel, Tanh is
+the head convolution's epilogue, and the 3-channel NCHW<->NHWC conversions are folded into the stem / head
+convolutions.  There is no CPU or eager-PyTorch path: tensors must be on the GPU and ``libmstg_hip.so`` must be
+built, otherwise the ops raise.
+
+Mirrors /root/reference/enhanced_generator.py: LocalAttention :6-47, MultiScaleBlock :49-84,
+EnhancedGenerator :86-228, EnhancedDiscriminator :230-274.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.utils.checkpoint
+
+from mstg_hip import ops
+from mstg_hip.layers import (HipConv2d, HipConvTranspose2d, HipInstanceNorm2d, HipLeakyReLU, HipReLU, HipTanh, to_nchw,
+                             to_nhwc)
+from mstg_hip.ops import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH
+from structural_transformer import StructuralTransformerBlock
+
+
+class LocalAttention(nn.Module):
+    """Windowed channel attention (reference :6-47).  ``forward`` takes/returns NCHW like the reference."""
+
+    def __init__(self, channels, window_size=8):
+        super().__init__()
+        self.window_size = window_size
+        self.qkv = HipConv2d(channels, channels * 3, 1)
+        self.proj = HipConv2d(channels, channels, 1)
+
+    def forward_nhwc(self, x):
+        ws = self.window_size
+        H, W = x.shape[1], x.shape[2]
+        if H % ws or W % ws:  # the reference's padding branch is broken and raises RuntimeError from .view (:15-23)
+            raise RuntimeError(f"LocalAttention: H and W must be multiples of window_size={ws}, got {H}x{W}")
+        if ws != 4:
+            raise RuntimeError("LocalAttention: the HIP kernel implements window_size=4 (the only value the reference uses)")
+        qkv = self.qkv(x, nhwc=True)
+        o = ops.WindowAttnCoreFn.apply(qkv)
+        return self.proj(o, nhwc=True)
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class MultiScaleBlock(nn.Module):
+    """1x1 + three dilated 3x3 branches, IN+ReLU each, concat, 1x1 fusion + IN + ReLU, residual (reference :49-84)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        c4 = channels // 4
+        self.branch1 = nn.Sequential(HipConv2d(channels, c4, 1), HipInstanceNorm2d(c4), HipReLU(True))
+        self.branch2 = nn.Sequential(HipConv2d(channels, c4, 3, padding=1, dilation=1), HipInstanceNorm2d(c4), HipReLU(True))
+        self.branch3 = nn.Sequential(HipConv2d(channels, c4, 3, padding=2, dilation=2), HipInstanceNorm2d(c4), HipReLU(True))
+        self.branch4 = nn.Sequential(HipConv2d(channels, c4, 3, padding=4, dilation=4), HipInstanceNorm2d(c4), HipReLU(True))
+        self.fusion = nn.Sequential(HipConv2d(channels, channels, 1), HipInstanceNorm2d(channels), HipReLU(True))
+
+    def forward_nhwc(self, x):
+        wb = []
+        for br in (self.branch1, self.branch2, self.branch3, self.branch4):
+            wb += [br[0].weight, br[0].bias]
+        cat = ops.MSBranchesFn.apply(x, *wb)          # 4 convs -> one (N,H,W,ch) buffer, no torch.cat
+        cat = ops.instnorm_act(cat, ACT_RELU)          # per-channel IN: one launch covers all four branches
+        f = self.fusion[0](cat, nhwc=True)
+        return ops.instnorm_act(f, ACT_RELU, residual=x)
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class _Stage(nn.Sequential):
+    """conv(T) -> IN -> ReLU -> LocalAttention -> MultiScaleBlock with the reference's child indices 0..4."""
+
+    def forward_nhwc(self, x):
+        x = self[0](x, nhwc=True)
+        x = ops.instnorm_act(x, ACT_RELU)
+        x = self[3].forward_nhwc(x)
+        return self[4].forward_nhwc(x)
+
+    def forward(self, x):
+        return to_nchw(self.forward_nhwc(to_nhwc(x)))
+
+
+class EnhancedGenerator(nn.Module):
+    def __init__(self, channels=64, num_transformer_blocks=3):
+        super().__init__()
+        C = channels
+        self.initial = nn.Sequential(HipConv2d(3, C, 7, 1, 3), HipInstanceNorm2d(C), HipReLU(True))
+        self.down1 = _Stage(HipConv2d(C, C * 2, 4, 2, 1), HipInstanceNorm2d(C * 2), HipReLU(True),
+                            LocalAttention(C * 2, window_size=4), MultiScaleBlock(C * 2))
+        self.down2 = _Stage(HipConv2d(C * 2, C * 4, 4, 2, 1), HipInstanceNorm2d(C * 4), HipReLU(True),
+                            LocalAttention(C * 4, window_size=4), MultiScaleBlock(C * 4))
+        self.transformer_blocks = nn.ModuleList([StructuralTransformerBlock(dim=C * 4) for _ in range(num_transformer_blocks)])
+        self.up1 = _Stage(HipConvTranspose2d(C * 4, C * 2, 4, 2, 1), HipInstanceNorm2d(C * 2), HipReLU(True),
+                          LocalAttention(C * 2, window_size=4), MultiScaleBlock(C * 2))
+        self.up2 = _Stage(HipConvTranspose2d(C * 2, C, 4, 2, 1), HipInstanceNorm2d(C), HipReLU(True),
+                          LocalAttention(C, window_size=4), MultiScaleBlock(C))
+        self.output = nn.Sequential(HipConv2d(C, 3, 7, 1, 3), HipTanh())
+        self.style_encoder = nn.Sequential(nn.AdaptiveAvgPool2d(1), nn.Flatten(), nn.Linear(C * 4, C * 4), nn.ReLU(True))
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):  # reference :152-161
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.InstanceNorm2d):
+            if m.weight is not None:
+                nn.init.constant_(m.weight, 1)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def gradient_checkpointing_enable(self):
+        """Recompute each stage in the backward (reference :163-177).  Results are identical either way; with 288 GB of
+        HBM it is off unless asked for."""
+        for m in (self.down1, self.down2, self.transformer_blocks, self.up1, self.up2):
+            m.requires_grad_(True)
+        self.use_checkpointing = True
+
+    def _run(self, fn, *args):
+        if getattr(self, "use_checkpointing", False) and torch.is_grad_enabled():
+            return torch.utils.checkpoint.checkpoint(fn, *args, use_reentrant=False)
+        return fn(*args)
+
+    def _style_vector(self, feat_nhwc):
+        pooled = ops.spatial_mean(feat_nhwc)  # AdaptiveAvgPool2d(1) + Flatten
+        lin = self.style_encoder[2]
+        return ops.activation(torch.addmm(lin.bias, pooled, lin.weight.t()), ACT_RELU)
+
+    def forward_taps(self, x, taps=None):
+        """forward() that optionally records stage outputs (NHWC) into ``taps`` -- used by the parity tests."""
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"EnhancedGenerator expects (N,3,H,W), got {tuple(x.shape)}")
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise RuntimeError(f"EnhancedGenerator: H and W must be multiples of 16 (two stride-2 stages and 4x4 windows), "
+                               f"got {x.shape[2]}x{x.shape[3]}")
+        orig_input = x
+        h = self.initial[0](x, nhwc=True, x_nchw=True)          # NCHW image -> NHWC features inside the stem conv
+        h = ops.instnorm_act(h, ACT_RELU)
+        if taps is not None: taps["initial"] = h
+        h = self._run(self.down1.forward_nhwc, h)
+        if taps is not None: taps["down1"] = h
+        h = self._run(self.down2.forward_nhwc, h)
+        if taps is not None: taps["down2"] = h
+        if len(self.transformer_blocks) > 0:
+            all_identity = all(getattr(b, "is_identity", False) for b in self.transformer_blocks)
+            style = None if all_identity else self._style_vector(h)
+            N, H4, W4, C4 = h.shape
+            tokens = h.reshape(N, H4 * W4, C4)                    # NHWC is already (B, HW, C) token-major (:218-219)
+            for block in self.transformer_blocks:
+                tokens = self._run(block, tokens, style, orig_input)
+            h = tokens.reshape(N, H4, W4, C4)
+        h = self._run(self.up1.forward_nhwc, h)
+        if taps is not None: taps["up1"] = h
+        h = self._run(self.up2.forward_nhwc, h)
+        if taps is not None: taps["up2"] = h
+        if taps is not None:
+            taps["pre_tanh"] = self.output[0](h, nhwc=True, y_nchw=True)
+        return self.output[0](h, nhwc=True, y_nchw=True, act=ACT_TANH)  # tanh fused, NHWC -> NCHW inside the head conv
+
+    def forward(self, x):
+        return self.forward_taps(x, None)
+
+
+class EnhancedDiscriminator(nn.Module):
+    def __init__(self, channels=64):
+        super().__init__()
+        C = channels
+        self.main = nn.Sequential(
+            HipConv2d(3, C, 4, 2, 1), HipLeakyReLU(0.2),
+            HipConv2d(C, C * 2, 4, 2, 1), HipInstanceNorm2d(C * 2), HipLeakyReLU(0.2),
+            HipConv2d(C * 2, C * 4, 4, 2, 1), HipInstanceNorm2d(C * 4), HipLeakyReLU(0.2),
+            HipConv2d(C * 4, C * 8, 4, 2, 1), HipInstanceNorm2d(C * 8), HipLeakyReLU(0.2),
+        )
+        self.batch_head = nn.Sequential(HipConv2d(C * 8, 1, 4, 1, 1), nn.AdaptiveAvgPool2d(1))
+        self.structure_head = nn.Sequential(HipConv2d(C * 8, C * 8, 3, 1, 1), HipInstanceNorm2d(C * 8), HipLeakyReLU(0.2),
+                                            HipConv2d(C * 8, 1, 4, 1, 1))
+        for m in self.modules():  # reference :269-271 -- the hook recomputes W/sigma (one power iteration) per forward
+            if isinstance(m, nn.Conv2d):
+                nn.utils.spectral_norm(m)
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"EnhancedDiscriminator expects (N,3,H,W), got {tuple(x.shape)}")
+        m = self.main
+        h = ops.activation(m[0](x, nhwc=True, x_nchw=True), ACT_LEAKY02)
+        for ci in (2, 5, 8):
+            h = ops.instnorm_act(m[ci](h, nhwc=True), ACT_LEAKY02)
+        N = h.shape[0]
+        score = ops.spatial_mean(self.batch_head[0](h, nhwc=True))             # (N, 1)
+        s = ops.instnorm_act(self.structure_head[0](h, nhwc=True), ACT_LEAKY02)
+        st = self.structure_head[3](s, nhwc=True)                               # (N, h, w, 1) == NCHW (N, 1, h, w)
+        return score.view(N, 1, 1, 1).squeeze(), st.permute(0, 3, 1, 2)

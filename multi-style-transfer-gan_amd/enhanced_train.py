@@ -1,0 +1,155 @@
+"""Drop-in for the reference's ``enhanced_train.EnhancedCycleGAN`` (enhanced_train.py:13-152) on MI355X kernels.
+
+Same surface: ``.G_AB .G_BA .D_A .D_B .g_optimizer .d_optimizer .criterion_* .lambda_*``,
+``train_step(real_A, real_B) -> {'d_loss','g_loss','cycle_loss','identity_loss','structure_loss'}`` (python
+floats) and ``save_models(save_dir, epoch)`` writing the reference's three checkpoint files.
+
+Differences, all deliberate:
+  * arithmetic is fp32 on the HIP kernels -- the parity target is the reference's CPU path, where
+    ``torch.cuda.amp.autocast`` / ``GradScaler`` disable themselves; ``.scaler`` is a no-op stand-in;
+  * the two Adam optimizers are ``FlatAdam`` (one fused launch, one contiguous gradient buffer each), and with
+    ``torch.distributed`` initialised each gradient buffer is averaged over ranks by one collective before its step;
+  * discriminator weight gradients are not computed during the generator phase (the reference computes and then
+    discards them at the next ``zero_grad``, enhanced_train.py:67,121);
+  * ``train_step_async`` returns the five losses as one device tensor with no host sync (the reference's
+    ``train_step`` does five ``.item()`` syncs, :125-131); ``train_step`` wraps it with a single sync;
+  * ctor takes keyword-only ``channels`` / ``num_transformer_blocks`` / ``device`` (defaults = reference values).
+"""
+from __future__ import annotations
+
+import itertools
+import os
+from pathlib import Path
+
+import torch
+
+from enhanced_generator import EnhancedDiscriminator, EnhancedGenerator
+from mstg_hip import dp, ops
+from mstg_hip.optim import FlatAdam
+
+LOSS_KEYS = ("d_loss", "g_loss", "cycle_loss", "identity_loss", "structure_loss")
+
+
+class _NoScaler:
+    """fp32 path: stands in for torch.cuda.amp.GradScaler (reference :46) so code touching ``.scaler`` keeps working."""
+
+    def scale(self, loss):
+        return loss
+
+    def step(self, optimizer):
+        return optimizer.step()
+
+    def update(self):
+        return None
+
+
+class _MeanLoss:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, a, b):
+        return self.fn(a, b)
+
+
+class EnhancedCycleGAN:
+    def __init__(self, pretrained_path=None, *, channels=16, num_transformer_blocks=1, device=None,
+                 gradient_checkpointing=False):
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("EnhancedCycleGAN (MI355X build) needs a GPU: there is no CPU path")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.G_AB = EnhancedGenerator(channels=channels, num_transformer_blocks=num_transformer_blocks).to(self.device)
+        self.G_BA = EnhancedGenerator(channels=channels, num_transformer_blocks=num_transformer_blocks).to(self.device)
+        self.D_A = EnhancedDiscriminator(channels=channels).to(self.device)
+        self.D_B = EnhancedDiscriminator(channels=channels).to(self.device)
+        if gradient_checkpointing:  # reference :24-25 turns it on for an 8 GB-class GPU; results are identical
+            self.G_AB.gradient_checkpointing_enable()
+            self.G_BA.gradient_checkpointing_enable()
+        if pretrained_path and os.path.exists(pretrained_path):
+            checkpoint = torch.load(pretrained_path, map_location=self.device, weights_only=True)
+            self.G_AB.load_state_dict(checkpoint["model_state_dict"], strict=False)
+            self.G_BA.load_state_dict(checkpoint["model_state_dict"], strict=False)
+        self._build_optimizers()
+        self.scaler = _NoScaler()
+        self.criterion_gan = _MeanLoss(ops.mse_loss)
+        self.criterion_cycle = _MeanLoss(ops.l1_loss)
+        self.criterion_identity = _MeanLoss(ops.l1_loss)
+        self.criterion_structure = _MeanLoss(ops.l1_loss)
+        self.lambda_cycle = 10.0
+        self.lambda_identity = 2.0
+        self.lambda_structure = 0.5
+
+    def _build_optimizers(self):
+        self.g_optimizer = FlatAdam(itertools.chain(self.G_AB.parameters(), self.G_BA.parameters()), lr=5e-5, betas=(0.5, 0.999))
+        self.d_optimizer = FlatAdam(itertools.chain(self.D_A.parameters(), self.D_B.parameters()), lr=2e-4, betas=(0.5, 0.999))
+        self._d_params = list(itertools.chain(self.D_A.parameters(), self.D_B.parameters()))
+
+    def sync_replicas(self):
+        """Make every rank start from rank 0's parameters and spectral-norm vectors (data-parallel runs)."""
+        dp.broadcast_(self.g_optimizer.flat)
+        dp.broadcast_(self.d_optimizer.flat)
+        for D in (self.D_A, self.D_B):
+            for b in D.buffers():
+                dp.broadcast_(b)
+
+    def train_step_async(self, real_A, real_B):
+        G_AB, G_BA, D_A, D_B = self.G_AB, self.G_BA, self.D_A, self.D_B
+        fake_B = G_AB(real_A)
+        fake_A = G_BA(real_B)
+        # ---- discriminator update (reference :67-85)
+        self.d_optimizer.zero_grad(set_to_none=True)
+        real_A_score, _ = D_A(real_A)
+        real_B_score, _ = D_B(real_B)
+        d_real_loss = (ops.mse_to_const(real_A_score, 1.0) + ops.mse_to_const(real_B_score, 1.0)) * 0.5
+        fake_A_score, _ = D_A(fake_A.detach())
+        fake_B_score, _ = D_B(fake_B.detach())
+        d_fake_loss = (ops.mse_to_const(fake_A_score, 0.0) + ops.mse_to_const(fake_B_score, 0.0)) * 0.5
+        d_loss = d_real_loss + d_fake_loss
+        d_loss.backward()
+        dp.allreduce_mean_(self.d_optimizer.grad)
+        self.d_optimizer.step()
+        # ---- generator update (reference :88-123); D weights take no gradient here (it would be discarded)
+        self.g_optimizer.zero_grad(set_to_none=True)
+        for p in self._d_params:
+            p.requires_grad_(False)
+        try:
+            idt_A = G_BA(real_A)
+            idt_B = G_AB(real_B)
+            identity_loss = (ops.l1_loss(idt_A, real_A) + ops.l1_loss(idt_B, real_B)) * self.lambda_identity
+            fake_A_score, fake_A_struct = D_A(fake_A)
+            fake_B_score, fake_B_struct = D_B(fake_B)
+            g_loss = ops.mse_to_const(fake_A_score, 1.0) + ops.mse_to_const(fake_B_score, 1.0)
+            recon_A = G_BA(fake_B)
+            recon_B = G_AB(fake_A)
+            cycle_loss = (ops.l1_loss(recon_A, real_A) + ops.l1_loss(recon_B, real_B)) * self.lambda_cycle
+            # The reference runs D on the fakes a second time for the structure heads (:110-113).  Outputs are the
+            # same function of the same inputs except for the spectral-norm power iteration that every train-mode
+            # forward performs, so the call count per D is kept at the reference's 5 per step.
+            with torch.no_grad():
+                _, real_A_struct = D_A(real_A)
+            _, fake_A_struct = D_A(fake_A)
+            with torch.no_grad():
+                _, real_B_struct = D_B(real_B)
+            _, fake_B_struct = D_B(fake_B)
+            structure_loss = (ops.l1_loss(real_A_struct, fake_A_struct) + ops.l1_loss(real_B_struct, fake_B_struct)) * self.lambda_structure
+            total_g_loss = g_loss + cycle_loss + identity_loss + structure_loss
+            total_g_loss.backward()
+        finally:
+            for p in self._d_params:
+                p.requires_grad_(True)
+        dp.allreduce_mean_(self.g_optimizer.grad)
+        self.g_optimizer.step()
+        return torch.stack([d_loss.detach(), g_loss.detach(), cycle_loss.detach(), identity_loss.detach(), structure_loss.detach()])
+
+    def train_step(self, real_A, real_B):
+        vals = self.train_step_async(real_A, real_B).tolist()  # one device sync
+        return dict(zip(LOSS_KEYS, vals))
+
+    def save_models(self, save_dir, epoch):  # reference :133-152
+        save_path = Path(save_dir)
+        save_path.mkdir(parents=True, exist_ok=True)
+        torch.save({"epoch": epoch, "G_AB_state_dict": self.G_AB.state_dict()}, save_path / f"G_AB_epoch_{epoch}.pth")
+        torch.save({"epoch": epoch, "G_BA_state_dict": self.G_BA.state_dict()}, save_path / f"G_BA_epoch_{epoch}.pth")
+        torch.save({"epoch": epoch, "D_A_state_dict": self.D_A.state_dict(), "D_B_state_dict": self.D_B.state_dict()},
+                   save_path / f"discriminators_epoch_{epoch}.pth")

@@ -1,0 +1,74 @@
+"""ctypes binding of libmstg_hip.so (include/mstg_hip.h).  No fallback: without the library every op raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmstg_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
+LOSS_L1, LOSS_MSE = 0, 1
+
+
+class ConvDesc(C.Structure):
+    """mirror of mstg_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "dil", "transposed",
+        "x_nchw", "y_nchw", "x_ctot", "x_coff", "y_ctot", "y_coff", "act", "accumulate")]
+
+
+_vp, _fp, _sz, _i, _f = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float
+_dp = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); the test-suite checks that every symbol declared in include/mstg_hip.h is here
+SIGNATURES = {
+    "mstg_version": (C.c_char_p, []),
+    "mstg_arch": (C.c_char_p, []),
+    "mstg_last_error": (C.c_char_p, []),
+    "mstg_conv2d_fwd": (_i, [_dp, _fp, _fp, _fp, _fp, _vp]),
+    "mstg_conv2d_dgrad": (_i, [_dp, _fp, _fp, _fp, _vp]),
+    "mstg_conv2d_wgrad_workspace_bytes": (_sz, [_dp]),
+    "mstg_conv2d_wgrad": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "mstg_norm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mstg_norm_act_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "mstg_norm_act_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "mstg_window_attn_core_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
+    "mstg_window_attn_core_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mstg_act_fwd": (_i, [_fp, _fp, _sz, _i, _vp]),
+    "mstg_act_bwd": (_i, [_fp, _fp, _fp, _sz, _i, _vp]),
+    "mstg_loss_workspace_bytes": (_sz, [_sz]),
+    "mstg_loss_mean_fwd": (_i, [_fp, _fp, _f, _sz, _i, _fp, _vp, _sz, _vp]),
+    "mstg_loss_mean_bwd": (_i, [_fp, _fp, _f, _sz, _i, _fp, _f, _fp, _fp, _vp]),
+    "mstg_channel_sum_workspace_bytes": (_sz, [_sz, _i]),
+    "mstg_channel_sum": (_i, [_fp, _sz, _i, _i, _i, _f, _fp, _vp, _sz, _vp]),
+    "mstg_plane_sum_workspace_bytes": (_sz, [_i, _i, _sz]),
+    "mstg_plane_sum": (_i, [_fp, _i, _i, _sz, _f, _fp, _vp, _sz, _vp]),
+    "mstg_segment_mean_fwd": (_i, [_fp, _i, _sz, _i, _fp, _vp]),
+    "mstg_segment_mean_bwd": (_i, [_fp, _i, _sz, _i, _fp, _vp]),
+    "mstg_adam_step_flat": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _i, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library once.  Raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -m mstg_hip.build` (or __graft_entry__.build()). "
+                "This package has no CPU or eager-PyTorch fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mstg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,334 @@
+// LocalAttention core (window 4x4 channel attention), forward and backward, fp32 MFMA, one wave per window.
+//
+// Per window (16 pixels, C channels):  S[c1][c2] = sum_p q^[p][c1] k^[p][c2],  P = softmax_c2(S),
+// O[p][c1] = sum_c2 P[c1][c2] V[p][c2].  All five small products of the backward are expressed through one
+// helper (tile_mma) that takes its operands from LDS tiles with arbitrary strides, so a transposed operand is a
+// stride swap, not a data movement.  The C x C attention matrix never leaves the CU; the backward recomputes it
+// from qkv.  Workgroup = one wave (64 threads): tiles are wave-private and need no cross-wave barriers.
+//
+// Reference site replaced: enhanced_generator.py:22-35,39-42 (view/permute/contiguous window partition, two
+// F.normalize, two batched matmuls, softmax, inverse permute).
+#include "common.h"
+
+namespace mstg {
+
+// acc[mf][nf] += A (16*MF x K) * B (K x 16*NF);  A(m,k) = Ap[m*a_sm + k*a_sk],  B(k,n) = Bp[k*b_sk + n*b_sn]
+template <int MF, int NF>
+__device__ __forceinline__ void tile_mma(f32x4 (&acc)[MF][NF], const float* Ap, int a_sm, int a_sk, const float* Bp, int b_sk,
+                                         int b_sn, int K, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const int k = k0 + g;
+        float a[MF], b[NF];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) a[mf] = Ap[(16 * mf + i) * a_sm + k * a_sk];
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) b[nf] = Bp[k * b_sk + (16 * nf + i) * b_sn];
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = mfma16(a[mf], b[nf], acc[mf][nf]);
+    }
+}
+
+template <int MF, int NF>
+__device__ __forceinline__ void tile_zero(f32x4 (&acc)[MF][NF]) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// D(m = 16mf + 4g + r, n = 16nf + i)  ->  Dp[m*d_sm + n*d_sn]
+template <int MF, int NF>
+__device__ __forceinline__ void tile_store(const f32x4 (&acc)[MF][NF], float* Dp, int d_sm, int d_sn, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Dp[(16 * mf + 4 * g + r) * d_sm + (16 * nf + i) * d_sn] = acc[mf][nf][r];
+}
+
+// sum over the 16 lanes that share lane>>4 (one accumulator row lives in 16 lanes)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+
+#define WAVE_SYNC() __syncthreads() /* one-wave workgroup: orders this wave's LDS writes before its reads */
+
+// CP = C rounded up to a multiple of 16 (16, 32 or 64).  LDS tiles (floats):
+//   qkv [16][3*CP + 4]   q^ | k^ | v blocks, zero-padded beyond C
+//   P   [CP][CP + 4]
+//   invn[2][16]          1/max(||q||,eps), 1/max(||k||,eps) per pixel
+template <int CP>
+struct AttnTiles {
+    static constexpr int LDQ = 3 * CP + 4, LDP = CP + 4, NF = CP / 16;
+    static constexpr int QKV = 0, P = 16 * LDQ, INVN = P + CP * LDP, END_FWD = INVN + 32;
+    // backward extras: dO [16][CP+4], dQK [16][2*CP+4]
+    static constexpr int LDO = CP + 4, LDK = 2 * CP + 4;
+    static constexpr int DO = END_FWD, DQK = DO + 16 * LDO, END_BWD = DQK + 16 * LDK;
+};
+
+// load one window of an (N,H,W,ctot) tensor into a [16][ld] LDS tile, `nblk` channel blocks of C -> CP padding
+template <int CP>
+__device__ __forceinline__ void load_window(const float* __restrict__ src, float* tile, int ld, int nblk, int C, int H, int W,
+                                            int n, int wy, int wx, int lane) {
+    const int qpb = CP / 4;  // float4 slots per block (padded)
+    const int ctot = nblk * C;
+    for (int e = lane; e < 16 * nblk * qpb; e += 64) {
+        const int q = e % qpb, rest = e / qpb;
+        const int blk = rest % nblk, p = rest / nblk;
+        const int y = 4 * wy + (p >> 2), x = 4 * wx + (p & 3);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (4 * q < C) v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + y) * W + x) * ctot + blk * C + 4 * q);
+        *reinterpret_cast<f32x4*>(&tile[p * ld + blk * CP + 4 * q]) = v;
+    }
+}
+
+// q^ , k^ , P into LDS; returns with tiles ready
+template <int CP>
+__device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
+    typedef AttnTiles<CP> T;
+    constexpr int NF = T::NF;
+    const int i = lane & 15, g = lane >> 4;
+    float* qkv = sm + T::QKV;
+    float* Ps = sm + T::P;
+    float* invn = sm + T::INVN;
+    // ---- L2 normalise q and k per pixel over channels (F.normalize: v / max(||v||, 1e-12)) ----------------------
+    {
+        float sq = 0.f, sk = 0.f;
+        const int c0 = g * (CP / 4);
+        for (int c = c0; c < c0 + CP / 4; ++c) {
+            const float a = qkv[i * T::LDQ + c], b = qkv[i * T::LDQ + CP + c];
+            sq += a * a;
+            sk += b * b;
+        }
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+        sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+        const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+        for (int c = c0; c < c0 + CP / 4; ++c) {
+            qkv[i * T::LDQ + c] *= iq;
+            qkv[i * T::LDQ + CP + c] *= ik;
+        }
+        if (g == 0) { invn[i] = iq; invn[16 + i] = ik; }
+    }
+    WAVE_SYNC();
+    // ---- S[c1][c2] = sum_p q^[p][c1] k^[p][c2] ; softmax over c2 (the 16 lanes of a row x NF fragments) ---------
+    f32x4 s[NF][NF];
+    tile_zero<NF, NF>(s);
+    tile_mma<NF, NF>(s, qkv, 1, T::LDQ, qkv + CP, T::LDQ, 1, 16, lane);
+#pragma unroll
+    for (int mf = 0; mf < NF; ++mf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                if (16 * nf + i >= C) s[mf][nf][r] = -INFINITY;
+                mx = fmaxf(mx, s[mf][nf][r]);
+            }
+            mx = row16_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                s[mf][nf][r] = __expf(s[mf][nf][r] - mx);
+                sum += s[mf][nf][r];
+            }
+            sum = row16_sum(sum);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) s[mf][nf][r] *= inv;
+        }
+    }
+    tile_store<NF, NF>(s, Ps, T::LDP, 1, lane);
+    WAVE_SYNC();
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void attn_core_fwd_kernel(const float* __restrict__ qkv_g, float* __restrict__ o_g, int N, int H,
+                                                           int W, int C) {
+    typedef AttnTiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        load_window<CP>(qkv_g, sm + T::QKV, T::LDQ, 3, C, H, W, n, wy, wx, lane);
+        WAVE_SYNC();
+        attn_forward_tiles<CP>(sm, C, lane);
+        // ---- O^T[c1][p] = sum_c2 P[c1][c2] V[p][c2] : rows = channels so a lane owns 4 consecutive channels ------
+        f32x4 o[NF][1];
+        tile_zero<NF, 1>(o);
+        tile_mma<NF, 1>(o, sm + T::P, T::LDP, 1, sm + T::QKV + 2 * CP, 1, T::LDQ, CP, lane);
+        const int y = 4 * wy + (i >> 2), x = 4 * wx + (i & 3);
+        float* dst = o_g + (((size_t)n * H + y) * W + x) * C;
+#pragma unroll
+        for (int mf = 0; mf < NF; ++mf) {
+            const int c = 16 * mf + 4 * g;
+            if (c < C) *reinterpret_cast<f32x4*>(dst + c) = o[mf][0];
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void attn_core_bwd_kernel(const float* __restrict__ qkv_g, const float* __restrict__ do_g,
+                                                           float* __restrict__ dqkv_g, int N, int H, int W, int C) {
+    typedef AttnTiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    float* qkv = sm + T::QKV;
+    float* Ps = sm + T::P;
+    float* invn = sm + T::INVN;
+    float* dOs = sm + T::DO;
+    float* dQK = sm + T::DQK;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        load_window<CP>(qkv_g, qkv, T::LDQ, 3, C, H, W, n, wy, wx, lane);
+        load_window<CP>(do_g, dOs, T::LDO, 1, C, H, W, n, wy, wx, lane);
+        WAVE_SYNC();
+        attn_forward_tiles<CP>(sm, C, lane);  // q^, k^ (in place), P, inverse norms
+
+        const int y = 4 * wy + (i >> 2), x = 4 * wx + (i & 3);
+        float* dst = dqkv_g + (((size_t)n * H + y) * W + x) * 3 * C;
+
+        // ---- dP[c1][c2] = sum_p dO[p][c1] V[p][c2] ; dS = P * (dP - rowsum(dP * P)) (kept in registers) ------------
+        f32x4 ds[NF][NF];
+        tile_zero<NF, NF>(ds);
+        tile_mma<NF, NF>(ds, dOs, 1, T::LDO, qkv + 2 * CP, T::LDQ, 1, 16, lane);
+#pragma unroll
+        for (int mf = 0; mf < NF; ++mf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr[NF], dot = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    pr[nf] = Ps[(16 * mf + 4 * g + r) * T::LDP + 16 * nf + i];
+                    dot += pr[nf] * ds[mf][nf][r];
+                }
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) ds[mf][nf][r] = pr[nf] * (ds[mf][nf][r] - dot);
+            }
+        }
+        // ---- dV^T[c2][p] = sum_c1 P[c1][c2] dO[p][c1]  (needs P: do it before P is overwritten by dS) -------------
+        {
+            f32x4 dv[NF][1];
+            tile_zero<NF, 1>(dv);
+            tile_mma<NF, 1>(dv, Ps, 1, T::LDP, dOs, 1, T::LDO, CP, lane);
+#pragma unroll
+            for (int mf = 0; mf < NF; ++mf) {
+                const int c = 16 * mf + 4 * g;
+                if (c < C) *reinterpret_cast<f32x4*>(dst + 2 * C + c) = dv[mf][0];
+            }
+        }
+        WAVE_SYNC();
+        tile_store<NF, NF>(ds, Ps, T::LDP, 1, lane);  // P <- dS
+        WAVE_SYNC();
+        // ---- dq^[p][c1] = sum_c2 dS[c1][c2] k^[p][c2] ; dk^[p][c2] = sum_c1 dS[c1][c2] q^[p][c1] -------------------
+        // normalisation backward needs a dot over channels per pixel: keep pixels on the accumulator rows.
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            f32x4 d[1][NF];
+            tile_zero<1, NF>(d);
+            if (which == 0) tile_mma<1, NF>(d, qkv + CP, T::LDQ, 1, Ps, 1, T::LDP, CP, lane);  // A = k^ (p x c2), B = dS^T
+            else tile_mma<1, NF>(d, qkv, T::LDQ, 1, Ps, T::LDP, 1, CP, lane);                  // A = q^ (p x c1), B = dS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 4 * g + r;
+                float hat[NF], dot = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    hat[nf] = qkv[p * T::LDQ + which * CP + 16 * nf + i];
+                    dot += hat[nf] * d[0][nf][r];
+                }
+                dot = row16_sum(dot);
+                const float inv = invn[which * 16 + p];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) dQK[p * T::LDK + which * CP + 16 * nf + i] = (d[0][nf][r] - hat[nf] * dot) * inv;
+            }
+        }
+        WAVE_SYNC();
+        // ---- write dq | dk (pixel-major tile -> NHWC) ---------------------------------------------------------------
+        for (int e = lane; e < 16 * 2 * (CP / 4); e += 64) {
+            const int q = e % (CP / 4), rest = e / (CP / 4);
+            const int blk = rest % 2, p = rest / 2;
+            if (4 * q < C) {
+                const int yy = 4 * wy + (p >> 2), xx = 4 * wx + (p & 3);
+                *reinterpret_cast<f32x4*>(dqkv_g + (((size_t)n * H + yy) * W + xx) * 3 * C + blk * C + 4 * q) =
+                    *reinterpret_cast<const f32x4*>(&dQK[p * T::LDK + blk * CP + 4 * q]);
+            }
+        }
+    }
+}
+
+static int attn_check(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "window_attn: empty tensor");
+    if (H % 4 || W % 4) return fail_arg(MSTG_E_BADARG, "window_attn: H and W must be multiples of the 4x4 window");
+    if (C % 4) return fail_arg(MSTG_E_ALIGN, "window_attn: C must be a multiple of 4");
+    if (C > 64) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn: C > 64 not implemented in this build");
+    return MSTG_OK;
+}
+
+template <int CP>
+static int launch_attn(bool bwd, const float* qkv, const float* d_o, float* out, int N, int H, int W, int C, hipStream_t st) {
+    typedef AttnTiles<CP> T;
+    const size_t lds = (size_t)(bwd ? T::END_BWD : T::END_FWD) * sizeof(float);
+    const int nwin = N * (H / 4) * (W / 4);
+    int grid = 256 * 8;
+    if (grid > nwin) grid = nwin;
+    if (bwd) {
+        static bool set = false;
+        if (!set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_bwd_kernel<CP>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_bwd)");
+            set = true;
+        }
+        hipLaunchKernelGGL((attn_core_bwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
+    } else {
+        hipLaunchKernelGGL((attn_core_fwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
+    }
+    MSTG_CHECK_LAUNCH("attn_core_kernel");
+    return MSTG_OK;
+}
+
+}  // namespace mstg
+
+using namespace mstg;
+
+extern "C" int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int H, int W, int C, void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!qkv || !o) return fail_arg(MSTG_E_BADARG, "window_attn_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 16) return launch_attn<16>(false, qkv, nullptr, o, N, H, W, C, st);
+    if (C <= 32) return launch_attn<32>(false, qkv, nullptr, o, N, H, W, C, st);
+    return launch_attn<64>(false, qkv, nullptr, o, N, H, W, C, st);
+}
+
+extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C,
+                                         void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!qkv || !d_o || !dqkv) return fail_arg(MSTG_E_BADARG, "window_attn_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (C <= 16) return launch_attn<16>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    if (C <= 32) return launch_attn<32>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    return launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
+}

@@ -1,0 +1,311 @@
+// Weight gradient of Conv2d / ConvTranspose2d(k4,s2,p1) on the fp32 MFMA of gfx950.
+//
+//   dW(gch, hch, tap) = sum_{n, gy, gx} G[n, gy*s - p + ky*d, gx*s - p + kx*d, gch] * Hh[n, gy, gx, hch]
+//
+// "G" is the tensor the filter taps are gathered from (Conv2d: the module input; ConvTranspose2d: the output
+// gradient), "Hh" the tensor living on the walked grid (Conv2d: the output gradient; ConvTranspose2d: the module
+// input).  GEMM view: M = 16 gathered channels, N = 16*NFH grid channels, K = pixels (4 per MFMA).  A workgroup
+// walks a strided set of 8x16 pixel tiles, keeping one accumulator fragment per tap in registers; the four waves
+// split the tile rows, are summed through LDS once at the end, and the per-workgroup partials are reduced by a
+// second tiny kernel in a fixed order (bit-reproducible: no atomics).
+//
+// Reference sites replaced: the wgrad half of convolution_backward for every conv on the path
+// (enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,237-265; pretrain.py:65-91).
+#include "common.h"
+
+namespace mstg {
+
+struct WGradArgs {
+    const float* g;   // gathered tensor
+    const float* h;   // grid tensor
+    float* partial;   // [S][T][Cg][Ch]
+    int N;
+    int gH, gW, g_ctot, g_coff, g_nchw, Cg;
+    int hH, hW, h_ctot, h_coff, h_nchw, Ch;  // hH x hW is the walked grid
+    int KH, KW, stride, pad, dil;
+    int tiles_x, tiles_y, ntiles;
+    int PH, PW;
+    int T;      // taps
+    int TGn;    // taps per z-slice
+    int n_gchunks;
+};
+
+constexpr int WT_H = 8, WT_W = 16, G_CKP = 20;
+
+// TG  : accumulator fragments (taps) per workgroup z-slice;  NFH : 16-wide grid-channel fragments per workgroup
+template <int TG, int NFH>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
+    constexpr int BN = 16 * NFH, BNP = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                        // [PH][PW][G_CKP]
+    float* ht = smem + ((a.PH * a.PW * G_CKP + 3) & ~3);        // [128][BNP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int gchunk = blockIdx.y % a.n_gchunks, htile = blockIdx.y / a.n_gchunks;
+    const int g0 = gchunk * 16, h0 = htile * BN;
+    const int t0 = blockIdx.z * a.TGn;
+    const int tn = min(a.TGn, a.T - t0);
+    const int s = a.stride;
+
+    f32x4 acc[TG][NFH];
+    int toff[TG];  // LDS offset of each tap inside the patch (wave-uniform, hoisted out of the pixel loops)
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        const int tt = min(t0 + t, a.T - 1);
+        toff[t] = (((tt / a.KW) * a.dil) * a.PW + (tt % a.KW) * a.dil) * G_CKP;
+#pragma unroll
+        for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
+        const int y0 = ty0 * WT_H * s - a.pad, x0 = tx0 * WT_W * s - a.pad;
+        __syncthreads();
+        // ---- stage gathered patch: 16 channels [g0, g0+16), zero beyond Cg and outside the image -------------
+        if (a.g_nchw) {
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int pc = lane; pc < a.PW; pc += 64) {
+                    const int ix = x0 + pc;
+                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                    float* dst = &patch[(pr * a.PW + pc) * G_CKP];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        float v = 0.f;
+                        if (inb && c < a.Cg) v = a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix];
+                        dst[c] = v;
+                    }
+                }
+            }
+        } else {
+            const bool al = ((a.g_ctot | a.g_coff) & 3) == 0;
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int e = lane; e < a.PW * 4; e += 64) {
+                    const int pc = e >> 2, q = e & 3;
+                    const int ix = x0 + pc;
+                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int c = g0 + 4 * q;
+                    if (inb && c < a.Cg) {
+                        const float* src = a.g + (((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c;
+                        if (al && c + 3 < a.Cg) {
+                            v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c + k < a.Cg) v[k] = src[k];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * G_CKP + 4 * q]) = v;
+                }
+            }
+        }
+        // ---- stage the grid tensor tile: 128 pixels x BN channels, zero outside ------------------------------
+        if (a.h_nchw) {
+            for (int c = wave; c < BN; c += 4) {
+                for (int p = lane; p < 128; p += 64) {
+                    const int gy = ty0 * WT_H + (p >> 4), gx = tx0 * WT_W + (p & 15);
+                    float v = 0.f;
+                    if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
+                        v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
+                    ht[p * BNP + c] = v;
+                }
+            }
+        } else {
+            const bool al = ((a.h_ctot | a.h_coff) & 3) == 0;
+            for (int e = tid; e < 128 * (BN / 4); e += 256) {
+                const int q = e % (BN / 4), p = e / (BN / 4);
+                const int gy = ty0 * WT_H + (p >> 4), gx = tx0 * WT_W + (p & 15);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int c = h0 + 4 * q;
+                if (gy < a.hH && gx < a.hW && c < a.Ch) {
+                    const float* src = a.h + (((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + c;
+                    if (al && c + 3 < a.Ch) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (c + k < a.Ch) v[k] = src[k];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&ht[p * BNP + 4 * q]) = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;
+#pragma unroll 1
+            for (int xs = 0; xs < 4; ++xs) {
+                const int c = 4 * xs + g;  // this lane's k-slot pixel column
+                float bf[NFH];
+#pragma unroll
+                for (int hf = 0; hf < NFH; ++hf) bf[hf] = ht[(r * 16 + c) * BNP + 16 * hf + i];
+#pragma unroll
+                for (int t = 0; t < TG; ++t) {
+                    if (t < tn) {
+                        const float af = patch[(r * s * a.PW + c * s) * G_CKP + toff[t] + i];
+#pragma unroll
+                        for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = mfma16(af, bf[hf], acc[t][hf]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- sum the four waves through LDS (fixed order), then write this workgroup's partial --------------------
+    __syncthreads();
+    float* red = smem;  // [TG*NFH][256]
+    for (int wv = 1; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int hf = 0; hf < NFH; ++hf) *reinterpret_cast<f32x4*>(&red[((t * NFH + hf) * 64 + lane) * 4]) = acc[t][hf];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t)
+#pragma unroll
+                for (int hf = 0; hf < NFH; ++hf) acc[t][hf] += *reinterpret_cast<const f32x4*>(&red[((t * NFH + hf) * 64 + lane) * 4]);
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float* out = a.partial + (size_t)blockIdx.x * a.T * a.Cg * a.Ch;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            if (t >= tn) continue;
+#pragma unroll
+            for (int hf = 0; hf < NFH; ++hf) {
+                const int hch = h0 + 16 * hf + i;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gch = g0 + 4 * g + e;
+                    if (gch < a.Cg && hch < a.Ch) out[((size_t)(t0 + t) * a.Cg + gch) * a.Ch + hch] = acc[t][hf][e];
+                }
+            }
+        }
+    }
+}
+
+// dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int T, int Cg, int Ch,
+                                    int s_g, int s_h) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = T * Cg * Ch;
+    if (idx >= total) return;
+    float sum = 0.f;
+    for (int sp = 0; sp < S; ++sp) sum += partial[(size_t)sp * total + idx];
+    const int hch = idx % Ch, gch = (idx / Ch) % Cg, t = idx / (Ch * Cg);
+    dw[(size_t)gch * s_g + (size_t)hch * s_h + t] = sum;
+}
+
+struct WGradPlan {
+    int S, TGn, nz, nfh, tg;
+    size_t ws_bytes;
+};
+
+static WGradPlan plan_wgrad(const WGradArgs& a) {
+    WGradPlan p;
+    p.nfh = a.Ch <= 16 ? 1 : 2;
+    if (a.T == 1) p.tg = 1;
+    else if (a.T <= 9) p.tg = 9;
+    else p.tg = 16;
+    p.nz = cdiv(a.T, p.tg);
+    p.TGn = cdiv(a.T, p.nz);
+    const int ny = cdiv(a.Cg, 16) * cdiv(a.Ch, 16 * p.nfh);
+    int S = 1024 / (ny * p.nz);
+    if (S < 1) S = 1;
+    if (S > a.ntiles) S = a.ntiles;
+    p.S = S;
+    p.ws_bytes = (size_t)S * a.T * a.Cg * a.Ch * sizeof(float);
+    return p;
+}
+
+template <int TG, int NFH>
+static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
+    constexpr int BNP = 16 * NFH + 4;
+    size_t lds = ((size_t)((a.PH * a.PW * G_CKP + 3) & ~3) + 128 * BNP) * sizeof(float);
+    const size_t red = (size_t)TG * NFH * 256 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: LDS patch too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TG, NFH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad)");
+        attr_set = true;
+    }
+    dim3 grid(p.S, cdiv(a.Cg, 16) * cdiv(a.Ch, 16 * NFH), p.nz);
+    hipLaunchKernelGGL((wgrad_kernel<TG, NFH>), grid, dim3(256), lds, st, a);
+    MSTG_CHECK_LAUNCH("wgrad_kernel");
+    return MSTG_OK;
+}
+
+static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float* dy, WGradArgs& a) {
+    a.N = d->N;
+    a.KH = d->KH; a.KW = d->KW; a.dil = d->dil; a.T = d->KH * d->KW;
+    if (d->transposed) {  // gathered = dY (stride 2, pad 1 over the module-input grid), grid tensor = x
+        a.g = dy; a.gH = d->Ho; a.gW = d->Wo; a.g_ctot = d->y_ctot; a.g_coff = d->y_coff; a.g_nchw = d->y_nchw; a.Cg = d->Cout;
+        a.h = x; a.hH = d->H; a.hW = d->W; a.h_ctot = d->x_ctot; a.h_coff = d->x_coff; a.h_nchw = d->x_nchw; a.Ch = d->Cin;
+        a.stride = 2; a.pad = 1;
+    } else {
+        a.g = x; a.gH = d->H; a.gW = d->W; a.g_ctot = d->x_ctot; a.g_coff = d->x_coff; a.g_nchw = d->x_nchw; a.Cg = d->Cin;
+        a.h = dy; a.hH = d->Ho; a.hW = d->Wo; a.h_ctot = d->y_ctot; a.h_coff = d->y_coff; a.h_nchw = d->y_nchw; a.Ch = d->Cout;
+        a.stride = d->stride; a.pad = d->pad;
+    }
+    a.tiles_x = cdiv(a.hW, WT_W);
+    a.tiles_y = cdiv(a.hH, WT_H);
+    a.ntiles = a.N * a.tiles_x * a.tiles_y;
+    a.PH = (WT_H - 1) * a.stride + (a.KH - 1) * a.dil + 1;
+    a.PW = (WT_W - 1) * a.stride + (a.KW - 1) * a.dil + 1;
+    a.n_gchunks = cdiv(a.Cg, 16);
+    if (a.g_nchw && a.Cg > 16) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: NCHW gathered tensor supports <= 16 channels");
+    return MSTG_OK;
+}
+
+int check_desc(const mstg_conv_desc* d);  // conv_igemm.hip
+
+}  // namespace mstg
+
+using namespace mstg;
+
+extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    WGradArgs a{};
+    if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
+    return plan_wgrad(a).ws_bytes;
+}
+
+extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    if (!x || !dy || !dw || !workspace) return fail_arg(MSTG_E_BADARG, "conv_wgrad: null pointer");
+    (void)dbias;  // bias gradients are produced by mstg_channel_sum (one more pass over dy); kept in the ABI for fusion
+    WGradArgs a{};
+    if (int rc = fill_wgrad_args(d, x, dy, a)) return rc;
+    const WGradPlan p = plan_wgrad(a);
+    if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+    a.partial = (float*)workspace;
+    a.TGn = p.TGn;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = MSTG_E_UNSUPPORTED;
+    if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
+    else if (p.tg == 1 && p.nfh == 2) rc = launch_wgrad_t<1, 2>(a, p, st);
+    else if (p.tg == 9 && p.nfh == 1) rc = launch_wgrad_t<9, 1>(a, p, st);
+    else if (p.tg == 9 && p.nfh == 2) rc = launch_wgrad_t<9, 2>(a, p, st);
+    else if (p.tg == 16 && p.nfh == 1) rc = launch_wgrad_t<16, 1>(a, p, st);
+    else if (p.tg == 16 && p.nfh == 2) rc = launch_wgrad_t<16, 2>(a, p, st);
+    if (rc) return rc;
+    const int T = a.T, total = T * a.Cg * a.Ch;
+    // Conv2d: dw[co][ci][t] (gch = ci, hch = co) ; ConvTranspose2d: dw[ci][co][t] (gch = co, hch = ci)
+    const int s_g = d->transposed ? T : T;
+    const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, a.partial, dw, p.S, T, a.Cg, a.Ch, s_g, s_h);
+    MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return MSTG_OK;
+}

@@ -1,0 +1,306 @@
+// HBM-bound element-wise and reduction kernels of the training step: activations, mean losses and their
+// gradients, per-channel sums (bias gradients / global average pool), flat Adam.
+// All reductions are two-stage with a fixed order (bit-reproducible, no float atomics).
+//
+// Reference sites replaced: nn.LeakyReLU(0.2) of the discriminator stem (enhanced_generator.py:238), nn.Tanh
+// backward (:138), nn.MSELoss / nn.L1Loss (enhanced_train.py:49-52,72-115), nn.AdaptiveAvgPool2d(1)
+// (enhanced_generator.py:257), conv bias gradients, torch.optim.Adam (enhanced_train.py:36-43).
+#include "common.h"
+
+namespace mstg {
+
+constexpr int EW_BLOCK = 256;
+constexpr int EW_MAX_BLOCKS = 2048;
+
+static int ew_grid(size_t n4) {
+    size_t b = cdivz(n4, EW_BLOCK);
+    if (b > EW_MAX_BLOCKS) b = EW_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        y[i] = apply_act(x[i], act);
+    }
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ xy, const float* __restrict__ dy, float* __restrict__ dx, size_t n, int act) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(xy)[i];
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= act_grad(v[e], act);
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        dx[i] = dy[i] * act_grad(xy[i], act);
+    }
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+    return r;  // valid in thread 0
+}
+
+__global__ void loss_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, float bconst, size_t n, int kind,
+                                    float* __restrict__ partial) {
+    __shared__ float sh[8];
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - (b ? b[i] : bconst);
+        acc += kind == 0 ? fabsf(d) : d * d;
+    }
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ partial, int nb, float inv_n, float* __restrict__ out) {
+    __shared__ float sh[8];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partial[i];
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = r * inv_n;
+}
+
+__global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float bconst, size_t n, int kind,
+                                const float* __restrict__ gscale, float scale, float* __restrict__ da, float* __restrict__ db) {
+    const float gs = (gscale ? gscale[0] : 1.f) * scale / (float)n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - (b ? b[i] : bconst);
+        float g;
+        if (kind == 0) g = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);  // torch: sign(0) = 0
+        else g = 2.f * d * gs;
+        da[i] = g;
+        if (db) db[i] = -g;
+    }
+}
+
+// out[c] = scale * sum_p x[p*ctot + coff + c], two stages: [nb][C] partials then a column sum
+__global__ void channel_sum_partial_kernel(const float* __restrict__ x, size_t P, int ctot, int coff, int C, float* __restrict__ partial) {
+    // thread t handles channel t % C for pixels (t / C) + k * (blockDim / C) of this block's pixel range
+    extern __shared__ float sh[];
+    const int rows = blockDim.x / C;
+    const int c = threadIdx.x % C, row = threadIdx.x / C;
+    const size_t per = (P + gridDim.x - 1) / gridDim.x;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < P ? p0 + per : P;
+    float acc = 0.f;
+    if (row < rows)
+        for (size_t p = p0 + row; p < p1; p += rows) acc += x[p * ctot + coff + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += sh[r * C + threadIdx.x];
+        partial[(size_t)blockIdx.x * C + threadIdx.x] = s;
+    }
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ partial, int nb, int C, float scale, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * C + c];
+    out[c] = s * scale;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, const unsigned char* __restrict__ mask) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (mask && !mask[i]) continue;
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        // torch.optim.Adam: denom = sqrt(v)/sqrt(bias_correction2) + eps ; p -= (lr / bias_correction1) * m / denom
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+// planar (NCHW) per-channel sum, stage 1: partial[b][c] = sum over a slice of the N*HW elements of channel c
+__global__ void plane_sum_partial_kernel(const float* __restrict__ x, int N, int C, size_t HW, float* __restrict__ partial) {
+    __shared__ float sh[8];
+    const int c = blockIdx.y;
+    const size_t total = (size_t)N * HW, stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t n = e / HW, i = e - n * HW;
+        acc += x[(n * C + c) * HW + i];
+    }
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * C + c] = r;
+}
+
+// out[s][c] = scale * sum_{p < P} x[(s*P + p)*C + c]   (global average pool: one workgroup per segment)
+__global__ void segment_sum_kernel(const float* __restrict__ x, size_t P, int C, float scale, float* __restrict__ out) {
+    extern __shared__ float sh[];
+    const int rows = blockDim.x / C;
+    const int c = threadIdx.x % C, row = threadIdx.x / C;
+    const float* xs = x + (size_t)blockIdx.x * P * C;
+    float acc = 0.f;
+    if (row < rows)
+        for (size_t p = row; p < P; p += rows) acc += xs[p * C + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        float s = 0.f;
+        for (int r = 0; r < rows; ++r) s += sh[r * C + threadIdx.x];
+        out[(size_t)blockIdx.x * C + threadIdx.x] = s * scale;
+    }
+}
+
+// dx[s][p][c] = scale * dy[s][c]
+__global__ void segment_broadcast_kernel(const float* __restrict__ dy, size_t P, int C, float scale, float* __restrict__ dx, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, per = P * C;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const size_t s_ = e / per, c = e % C;
+        dx[e] = dy[s_ * C + c] * scale;
+    }
+}
+
+static int channel_sum_blocks(size_t P) {
+    size_t nb = cdivz(P, 256);
+    if (nb > 512) nb = 512;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace mstg
+
+using namespace mstg;
+
+extern "C" int mstg_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
+    if (!x || !y) return fail_arg(MSTG_E_BADARG, "act_fwd: null pointer");
+    if (n == 0) return MSTG_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, n, act);
+    MSTG_CHECK_LAUNCH("act_fwd_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_act_bwd(const float* x_or_y, const float* dy, float* dx, size_t n, int act, void* stream) {
+    if (!x_or_y || !dy || !dx) return fail_arg(MSTG_E_BADARG, "act_bwd: null pointer");
+    if (n == 0) return MSTG_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x_or_y, dy, dx, n, act);
+    MSTG_CHECK_LAUNCH("act_bwd_kernel");
+    return MSTG_OK;
+}
+
+extern "C" size_t mstg_loss_workspace_bytes(size_t n) {
+    (void)n;
+    return (size_t)EW_MAX_BLOCKS * sizeof(float);
+}
+
+extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, size_t n, int kind, float* out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!a || !out || !workspace) return fail_arg(MSTG_E_BADARG, "loss_fwd: null pointer");
+    if (n == 0) return fail_arg(MSTG_E_BADARG, "loss_fwd: empty tensor");
+    if (kind != 0 && kind != 1) return fail_arg(MSTG_E_BADARG, "loss_fwd: kind must be 0 (L1) or 1 (MSE)");
+    if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "loss_fwd: workspace too small");
+    const int nb = ew_grid(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, bconst, n, kind, (float*)workspace);
+    MSTG_CHECK_LAUNCH("loss_partial_kernel");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
+    MSTG_CHECK_LAUNCH("loss_final_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, size_t n, int kind, const float* gscale, float scale,
+                                  float* da, float* db, void* stream) {
+    if (!a || !da) return fail_arg(MSTG_E_BADARG, "loss_bwd: null pointer");
+    if (n == 0) return fail_arg(MSTG_E_BADARG, "loss_bwd: empty tensor");
+    if (kind != 0 && kind != 1) return fail_arg(MSTG_E_BADARG, "loss_bwd: kind must be 0 (L1) or 1 (MSE)");
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, bconst, n, kind, gscale, scale, da, db);
+    MSTG_CHECK_LAUNCH("loss_bwd_kernel");
+    return MSTG_OK;
+}
+
+extern "C" size_t mstg_channel_sum_workspace_bytes(size_t P, int C) {
+    if (C <= 0) return 0;
+    return (size_t)channel_sum_blocks(P) * C * sizeof(float);
+}
+
+extern "C" int mstg_channel_sum(const float* x, size_t P, int ctot, int coff, int C, float scale, float* out, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace) return fail_arg(MSTG_E_BADARG, "channel_sum: null pointer");
+    if (P == 0 || C <= 0 || C > 1024 || ctot < coff + C) return fail_arg(MSTG_E_BADARG, "channel_sum: bad shape");
+    if (workspace_bytes < mstg_channel_sum_workspace_bytes(P, C)) return fail_arg(MSTG_E_WORKSPACE, "channel_sum: workspace too small");
+    const int nb = channel_sum_blocks(P);
+    const int threads = C <= 256 ? 256 : 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nb), dim3(threads), threads * sizeof(float), st, x, P, ctot, coff, C, (float*)workspace);
+    MSTG_CHECK_LAUNCH("channel_sum_partial_kernel");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
+    return MSTG_OK;
+}
+
+extern "C" size_t mstg_plane_sum_workspace_bytes(int N, int C, size_t HW) {
+    if (N <= 0 || C <= 0) return 0;
+    return (size_t)channel_sum_blocks((size_t)N * HW) * C * sizeof(float);
+}
+
+extern "C" int mstg_plane_sum(const float* x, int N, int C, size_t HW, float scale, float* out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    if (!x || !out || !workspace) return fail_arg(MSTG_E_BADARG, "plane_sum: null pointer");
+    if (N <= 0 || C <= 0 || C > 1024 || HW == 0) return fail_arg(MSTG_E_BADARG, "plane_sum: bad shape");
+    if (workspace_bytes < mstg_plane_sum_workspace_bytes(N, C, HW)) return fail_arg(MSTG_E_WORKSPACE, "plane_sum: workspace too small");
+    const int nb = channel_sum_blocks((size_t)N * HW);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(plane_sum_partial_kernel, dim3(nb, C), dim3(256), 0, st, x, N, C, HW, (float*)workspace);
+    MSTG_CHECK_LAUNCH("plane_sum_partial_kernel");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_segment_mean_fwd(const float* x, int S, size_t P, int C, float* out, void* stream) {
+    if (!x || !out) return fail_arg(MSTG_E_BADARG, "segment_mean: null pointer");
+    if (S <= 0 || P == 0 || C <= 0 || C > 1024) return fail_arg(MSTG_E_BADARG, "segment_mean: bad shape");
+    const int threads = C <= 256 ? 256 : 1024;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(S), dim3(threads), threads * sizeof(float), (hipStream_t)stream, x, P, C, 1.f / (float)P, out);
+    MSTG_CHECK_LAUNCH("segment_sum_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, float* dx, void* stream) {
+    if (!dy || !dx) return fail_arg(MSTG_E_BADARG, "segment_mean_bwd: null pointer");
+    if (S <= 0 || P == 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "segment_mean_bwd: bad shape");
+    const size_t total = (size_t)S * P * C;
+    hipLaunchKernelGGL(segment_broadcast_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dy, P, C, 1.f / (float)P, dx, total);
+    MSTG_CHECK_LAUNCH("segment_broadcast_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                                   float eps, int step, const unsigned char* mask, void* stream) {
+    if (!p || !g || !m || !v) return fail_arg(MSTG_E_BADARG, "adam: null pointer");
+    if (step < 1) return fail_arg(MSTG_E_BADARG, "adam: step counts from 1");
+    if (n == 0) return MSTG_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), mask);
+    MSTG_CHECK_LAUNCH("adam_kernel");
+    return MSTG_OK;
+}

@@ -1,0 +1,231 @@
+// InstanceNorm2d(affine=False) / BatchNorm2d fused with the following activation (and an optional residual add),
+// forward and backward, on NHWC fp32.  HBM-bound: the forward reads x twice (statistics, then normalise -- the
+// second read of a per-image slab normally hits L2 / Infinity Cache) and writes y once.
+//
+// Numerics: sums are taken around a per-channel pivot (the first pixel) so that E[(x-K)^2] - E[x-K]^2 does not
+// cancel when |mean| >> std; partial sums per (image, split) are combined in a fixed order (bit-reproducible).
+//
+// Reference sites replaced: nn.InstanceNorm2d + nn.ReLU/nn.LeakyReLU(0.2) (enhanced_generator.py:54-75,93-94,
+// 100-101,107-108,122-123,129-130,242-251,263-264), the residual `+ x` (:84), nn.BatchNorm2d (pretrain.py:69-89).
+#include "common.h"
+
+namespace mstg {
+
+constexpr float NORM_EPS = 1e-5f;
+
+struct NormGeom {
+    int N, HW, C, split, chunk;  // chunk = pixels per split
+};
+
+static NormGeom norm_geom(int N, int HW, int C) {
+    NormGeom g;
+    g.N = N; g.HW = HW; g.C = C;
+    int split = 1024 / (N > 0 ? N : 1);
+    if (split < 1) split = 1;
+    const int maxsplit = cdiv(HW, 64);
+    if (split > maxsplit) split = maxsplit;
+    g.chunk = cdiv(HW, split);
+    g.split = cdiv(HW, g.chunk);
+    return g;
+}
+
+// partial[(n*split + sp)*2*C + {0,1}*C + c]
+template <bool BWD>
+__global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ partial,
+                                                           NormGeom g, int act, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [rows][2][C]
+    const int C = g.C, C4 = C >> 2, rows = 256 / C4;
+    const int sp = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int q = tid % C4, row = tid / C4;
+    const int p0 = sp * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+    const float* xb = x + (size_t)n * g.HW * C;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+        if (!BWD) {
+            const f32x4 K = *reinterpret_cast<const f32x4*>((batch ? x : xb) + 4 * q);
+            for (int p = p0 + row; p < p1; p += rows) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + 4 * q) - K;
+                s1 += v;
+                s2 += v * v;
+            }
+        } else {
+            const float* st = stats + (size_t)(batch ? 0 : n) * C * 2;
+            f32x4 mu, rs, ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mu[e] = st[(4 * q + e) * 2]; rs[e] = st[(4 * q + e) * 2 + 1]; }
+            if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
+            const float* dyb = dy + (size_t)n * g.HW * C;
+            for (int p = p0 + row; p < p1; p += rows) {
+                const f32x4 xh = (*reinterpret_cast<const f32x4*>(xb + (size_t)p * C + 4 * q) - mu) * rs;
+                f32x4 gg = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gg[e] *= act_grad(xh[e] * ga[e] + be[e], act);
+                s1 += gg;
+                s2 += gg * xh;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&red[(row * 2 + 0) * C + 4 * q]) = s1;
+        *reinterpret_cast<f32x4*>(&red[(row * 2 + 1) * C + 4 * q]) = s2;
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * C; e += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < rows; ++r) acc += red[r * 2 * C + e];
+        partial[((size_t)n * g.split + sp) * 2 * C + e] = acc;
+    }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ residual, float* __restrict__ out,
+                                                         float* __restrict__ stats, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, const float* __restrict__ partial,
+                                                         NormGeom g, int act, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][C]: a, b (+ mu, rs for backward)
+    const int C = g.C, C4 = C >> 2, rows = 256 / C4;
+    const int sp = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const float cnt = batch ? (float)g.N * (float)g.HW : (float)g.HW;
+    for (int c = tid; c < C; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        if (batch != 2) {
+            const int nb = batch ? 0 : n, ne = batch ? g.N : n + 1;
+            for (int nn = nb; nn < ne; ++nn)
+                for (int s = 0; s < g.split; ++s) {
+                    t1 += partial[((size_t)nn * g.split + s) * 2 * C + c];
+                    t2 += partial[((size_t)nn * g.split + s) * 2 * C + C + c];
+                }
+        }
+        if (!BWD) {
+            float mean, rstd;
+            if (batch == 2) {
+                mean = running_mean[c];
+                rstd = rsqrtf(running_var[c] + NORM_EPS);
+            } else {
+                const float K = (batch ? x : x + (size_t)n * g.HW * C)[c];
+                const float e1 = t1 / cnt;
+                float var = t2 / cnt - e1 * e1;
+                var = var > 0.f ? var : 0.f;
+                mean = K + e1;
+                rstd = rsqrtf(var + NORM_EPS);
+                if (batch == 1 && sp == 0 && n == 0) {
+                    running_mean[c] = 0.9f * running_mean[c] + 0.1f * mean;
+                    running_var[c] = 0.9f * running_var[c] + 0.1f * var * (cnt / fmaxf(cnt - 1.f, 1.f));
+                }
+            }
+            if (sp == 0 && (!batch || n == 0)) {
+                stats[((size_t)(batch ? 0 : n) * C + c) * 2] = mean;
+                stats[((size_t)(batch ? 0 : n) * C + c) * 2 + 1] = rstd;
+            }
+            const float ga = batch ? gamma[c] : 1.f, be = batch ? beta[c] : 0.f;
+            sm[c] = rstd * ga;                 // y = (x - mean) * a + b
+            sm[C + c] = be;
+            sm[2 * C + c] = mean;
+        } else {
+            const float* st = stats + (size_t)(batch ? 0 : n) * C * 2;
+            const float mu = st[c * 2], rs = st[c * 2 + 1];
+            const float ga = batch ? gamma[c] : 1.f;
+            const float m1 = batch == 2 ? 0.f : t1 / cnt, m2 = batch == 2 ? 0.f : t2 / cnt;
+            if (batch == 1 && sp == 0 && n == 0) { dgamma[c] = t2; dbeta[c] = t1; }
+            sm[c] = mu;
+            sm[C + c] = rs;
+            sm[2 * C + c] = m1;
+            sm[3 * C + c] = m2;
+            (void)ga;
+        }
+    }
+    __syncthreads();
+    const int q = tid % C4, row = tid / C4;
+    if (row >= rows) return;
+    const int p0 = sp * g.chunk, p1 = min(g.HW, p0 + g.chunk);
+    const size_t base = (size_t)n * g.HW * C;
+    if (!BWD) {
+        const f32x4 A = *reinterpret_cast<const f32x4*>(&sm[4 * q]), B = *reinterpret_cast<const f32x4*>(&sm[C + 4 * q]);
+        const f32x4 M = *reinterpret_cast<const f32x4*>(&sm[2 * C + 4 * q]);
+        for (int p = p0 + row; p < p1; p += rows) {
+            const size_t o = base + (size_t)p * C + 4 * q;
+            f32x4 v = (*reinterpret_cast<const f32x4*>(x + o) - M) * A + B;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+            if (residual) v += *reinterpret_cast<const f32x4*>(residual + o);
+            *reinterpret_cast<f32x4*>(out + o) = v;
+        }
+    } else {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(&sm[4 * q]), rs = *reinterpret_cast<const f32x4*>(&sm[C + 4 * q]);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(&sm[2 * C + 4 * q]), m2 = *reinterpret_cast<const f32x4*>(&sm[3 * C + 4 * q]);
+        f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+        if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
+        for (int p = p0 + row; p < p1; p += rows) {
+            const size_t o = base + (size_t)p * C + 4 * q;
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * rs;
+            f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg[e] *= act_grad(xh[e] * ga[e] + be[e], act);
+            *reinterpret_cast<f32x4*>(out + o) = rs * ga * (gg - m1 - xh * m2);
+        }
+    }
+}
+
+static int norm_check(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "norm: empty tensor");
+    if (C % 4 || C > 1024) return fail_arg(MSTG_E_ALIGN, "norm: C must be a multiple of 4 and <= 1024");
+    return MSTG_OK;
+}
+
+}  // namespace mstg
+
+using namespace mstg;
+
+extern "C" size_t mstg_norm_workspace_bytes(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    const NormGeom g = norm_geom(N, HW, C);
+    return (size_t)N * g.split * 2 * C * sizeof(float);
+}
+
+extern "C" int mstg_norm_act_fwd(const float* x, const float* residual, float* y, float* stats, int N, int HW, int C, int act,
+                                 int batch_stats, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = norm_check(N, HW, C)) return rc;
+    if (!x || !y || !stats || !workspace) return fail_arg(MSTG_E_BADARG, "norm_fwd: null pointer");
+    if (batch_stats && (!gamma || !beta || !running_mean || !running_var)) return fail_arg(MSTG_E_BADARG, "norm_fwd: batch norm needs gamma/beta/running stats");
+    if (act == MSTG_ACT_TANH) return fail_arg(MSTG_E_UNSUPPORTED, "norm_fwd: tanh epilogue not supported");
+    const NormGeom g = norm_geom(N, HW, C);
+    if (workspace_bytes < mstg_norm_workspace_bytes(N, HW, C)) return fail_arg(MSTG_E_WORKSPACE, "norm_fwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = 256 / (C / 4);
+    dim3 grid(g.split, N);
+    if (batch_stats != 2) {
+        hipLaunchKernelGGL((norm_partial_kernel<false>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr, nullptr,
+                           gamma, beta, (float*)workspace, g, act, batch_stats);
+        MSTG_CHECK_LAUNCH("norm_partial_kernel");
+    }
+    hipLaunchKernelGGL((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats,
+                       gamma, beta, running_mean, running_var, nullptr, nullptr, (const float*)workspace, g, act, batch_stats);
+    MSTG_CHECK_LAUNCH("norm_apply_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_norm_act_bwd(const float* x, const float* stats, const float* dy, float* dx, int N, int HW, int C, int act,
+                                 int batch_stats, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = norm_check(N, HW, C)) return rc;
+    if (!x || !stats || !dy || !dx || !workspace) return fail_arg(MSTG_E_BADARG, "norm_bwd: null pointer");
+    if (batch_stats == 1 && (!gamma || !beta || !dgamma || !dbeta)) return fail_arg(MSTG_E_BADARG, "norm_bwd: batch norm needs gamma/beta/dgamma/dbeta");
+    if (batch_stats == 2) return fail_arg(MSTG_E_UNSUPPORTED, "norm_bwd: eval-mode batch norm backward not implemented");
+    const NormGeom g = norm_geom(N, HW, C);
+    if (workspace_bytes < mstg_norm_workspace_bytes(N, HW, C)) return fail_arg(MSTG_E_WORKSPACE, "norm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = 256 / (C / 4);
+    dim3 grid(g.split, N);
+    hipLaunchKernelGGL((norm_partial_kernel<true>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, dy, stats, gamma, beta,
+                       (float*)workspace, g, act, batch_stats);
+    MSTG_CHECK_LAUNCH("norm_partial_kernel<bwd>");
+    hipLaunchKernelGGL((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx,
+                       const_cast<float*>(stats), gamma, beta, nullptr, nullptr, dgamma, dbeta, (const float*)workspace, g, act,
+                       batch_stats);
+    MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
+    return MSTG_OK;
+}

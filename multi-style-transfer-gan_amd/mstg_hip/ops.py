@@ -1,0 +1,444 @@
+"""torch.autograd bindings of the HIP kernels.
+
+PyTorch is used for what it is good at here -- device memory (caching allocator), streams and the autograd
+graph -- while every arithmetic op of the hot path is a hand-written gfx950 kernel reached through the C ABI
+of ``libmstg_hip.so`` (include/mstg_hip.h).  Activations between ops are fp32 NHWC-contiguous tensors of shape
+(N, H, W, C); only the 3-channel image tensors at the module boundary are NCHW.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH, LOSS_L1, LOSS_MSE, ConvDesc  # noqa: F401
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------------------------------
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: Tensor, name: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"mstg_hip: {name} must live on the GPU (this package has no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"mstg_hip: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16) // 4 + 1, dtype=torch.float32, device=device)
+
+
+def conv_out_hw(H, W, k, stride, pad, dil, transposed):
+    if transposed:
+        return (H - 1) * stride - 2 * pad + dil * (k - 1) + 1, (W - 1) * stride - 2 * pad + dil * (k - 1) + 1
+    return (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed=0, x_nchw=0, y_nchw=0, x_ctot=None, x_coff=0,
+              y_ctot=None, y_coff=0, act=ACT_NONE, accumulate=0) -> ConvDesc:
+    return ConvDesc(N, H, W, Cin, Ho, Wo, Cout, k, k, stride, pad, dil, int(transposed), int(x_nchw), int(y_nchw),
+                    Cin if x_ctot is None else x_ctot, x_coff, Cout if y_ctot is None else y_ctot, y_coff, act, int(accumulate))
+
+
+class KernelTimer:
+    """Opt-in per-launch timing with HIP events on the launch stream (torch's current stream), used by bench.py for the
+    roofline figure.  Each record: (kernel symbol, start event, end event, algorithmic flops, algorithmic bytes)."""
+    enabled = False
+    records = []
+
+    @classmethod
+    def summary(cls):
+        """{symbol: dict(launches, ms, flops, bytes)} -- call after torch.cuda.synchronize()."""
+        out = {}
+        for sym, s, e, fl, by in cls.records:
+            r = out.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            r["launches"] += 1
+            r["ms"] += s.elapsed_time(e)
+            r["flops"] += fl
+            r["bytes"] += by
+        return out
+
+
+def _timed(sym, flops, nbytes, fn):
+    if not KernelTimer.enabled:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    fn()
+    e.record()
+    KernelTimer.records.append((sym, s, e, float(flops), float(nbytes)))
+
+
+def _conv_cost(d: ConvDesc):
+    """Algorithmic work of one convolution pass: 2*MACs, and read-input-once + write-output-once + weights-once bytes."""
+    T = d.KH * d.KW
+    macs = d.N * (d.H * d.W if d.transposed else d.Ho * d.Wo) * d.Cin * d.Cout * T
+    nbytes = 4 * (d.N * d.H * d.W * d.Cin + d.N * d.Ho * d.Wo * d.Cout + d.Cin * d.Cout * T)
+    return 2 * macs, nbytes
+
+
+def _igemm_symbol(cr, co, src_nchw):
+    v = 1 if src_nchw else (4 if cr % 16 == 0 else (2 if cr % 8 == 0 else 1))
+    return f"igemm_kernel<{v},{1 if co <= 16 else (2 if co <= 32 else 4)}>"
+
+
+def conv_fwd_raw(d: ConvDesc, x, w, b, y):
+    fl, by = _conv_cost(d)
+    _timed(_igemm_symbol(d.Cin, d.Cout, d.x_nchw), fl, by, lambda: _lib.check(
+        _lib.load().mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _stream()), "mstg_conv2d_fwd"))
+
+
+def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
+    fl, by = _conv_cost(d)
+    _timed(_igemm_symbol(d.Cout, d.Cin, d.y_nchw), fl, by, lambda: _lib.check(
+        _lib.load().mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _stream()), "mstg_conv2d_dgrad"))
+
+
+def conv_wgrad_raw(d: ConvDesc, x, dy, dw):
+    lib = _lib.load()
+    nbytes = lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = _ws(nbytes, x.device)
+    fl, by = _conv_cost(d)
+    T = d.KH * d.KW
+    ch = d.Cin if d.transposed else d.Cout
+    sym = f"wgrad_kernel<{1 if T == 1 else (9 if T <= 9 else 16)},{1 if ch <= 16 else 2}>"
+    _timed(sym, fl, by, lambda: _lib.check(
+        lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), None, _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"))
+
+
+def channel_sum(x: Tensor, P: int, ctot: int, coff: int, Cn: int, scale: float = 1.0) -> Tensor:
+    """out[c] = scale * sum_p x[p, coff + c] over an NHWC tensor viewed as (P, ctot)."""
+    lib = _lib.load()
+    out = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mstg_channel_sum_workspace_bytes(P, Cn), x.device)
+    _lib.check(lib.mstg_channel_sum(_p(x), P, ctot, coff, Cn, scale, _p(out), _p(ws), ws.numel() * 4, _stream()),
+               "mstg_channel_sum")
+    return out
+
+
+def plane_sum_nchw(x: Tensor) -> Tensor:
+    """out[c] = sum_{n,h,w} x[n,c,h,w] for the 3-channel NCHW image tensors."""
+    lib = _lib.load()
+    N, Cn, H, W = x.shape
+    out = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    ws = _ws(lib.mstg_plane_sum_workspace_bytes(N, Cn, H * W), x.device)
+    _lib.check(lib.mstg_plane_sum(_p(x), N, Cn, H * W, 1.0, _p(out), _p(ws), ws.numel() * 4, _stream()), "mstg_plane_sum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# convolution (Conv2d / ConvTranspose2d k4 s2 p1)
+# ----------------------------------------------------------------------------------------------------------
+class ConvFn(torch.autograd.Function):
+    """y = conv(x, w) + b [tanh].  cfg = (k, stride, pad, dil, transposed, x_nchw, y_nchw, act)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        k, stride, pad, dil, transposed, x_nchw, y_nchw, act = cfg
+        x, w = _req(x, "conv input"), _req(w, "conv weight")
+        b = None if b is None else _req(b, "conv bias")
+        if x_nchw:
+            N, Cin, H, W = x.shape
+        else:
+            N, H, W, Cin = x.shape
+        Cout = w.shape[1] if transposed else w.shape[0]
+        if (w.shape[0] if transposed else w.shape[1]) != Cin:
+            raise RuntimeError(f"mstg_hip conv: weight {tuple(w.shape)} does not match {Cin} input channels")
+        Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, transposed)
+        if Ho <= 0 or Wo <= 0:
+            raise RuntimeError(f"mstg_hip conv: input {H}x{W} too small for kernel {k} (stride {stride}, pad {pad}, dil {dil})")
+        y = torch.empty((N, Cout, Ho, Wo) if y_nchw else (N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
+        conv_fwd_raw(d, x, w, b, y)
+        ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
+        ctx.save_for_backward(x, w, y if act == ACT_TANH else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        k, stride, pad, dil, transposed, x_nchw, y_nchw, act = ctx.cfg
+        N, H, W, Cin, Ho, Wo, Cout = ctx.dims
+        x, w, y = ctx.saved_tensors
+        dy = _req(dy, "conv grad_output")
+        if act == ACT_TANH:
+            dy = act_bwd_raw(y, dy, ACT_TANH)
+        d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv_dgrad_raw(d, dy, w, dx)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            conv_wgrad_raw(d, x, dy, dw)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = plane_sum_nchw(dy) if y_nchw else channel_sum(dy, N * Ho * Wo, Cout, 0, Cout)
+        return dx, dw, db, None
+
+
+def conv2d(x, w, b, k, stride=1, pad=0, dil=1, transposed=False, x_nchw=False, y_nchw=False, act=ACT_NONE):
+    return ConvFn.apply(x, w, b, (k, stride, pad, dil, int(transposed), int(x_nchw), int(y_nchw), act))
+
+
+class MSBranchesFn(torch.autograd.Function):
+    """The four parallel branch convolutions of MultiScaleBlock (enhanced_generator.py:52-71,79-83) writing straight
+    into the channel-concatenated buffer: 1x1, 3x3 d1, 3x3 d2, 3x3 d4, each ch -> ch/4.  No torch.cat copy."""
+
+    GEOM = ((1, 0, 1), (3, 1, 1), (3, 2, 2), (3, 4, 4))  # (k, pad, dil)
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x = _req(x, "multi-scale input")
+        ws = [_req(t, "branch weight") for t in wb[0::2]]
+        bs = [_req(t, "branch bias") for t in wb[1::2]]
+        N, H, W, ch = x.shape
+        c4 = ws[0].shape[0]
+        y = torch.empty((N, H, W, 4 * c4), dtype=torch.float32, device=x.device)
+        for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
+            d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4)
+            conv_fwd_raw(d, x, ws[j], bs[j], y)
+        ctx.dims = (N, H, W, ch, c4)
+        ctx.save_for_backward(x, *ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, ch, c4 = ctx.dims
+        x, *ws = ctx.saved_tensors
+        dy = _req(dy, "multi-scale grad_output")
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        grads = []
+        for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
+            d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4, accumulate=int(j > 0))
+            if dx is not None:
+                conv_dgrad_raw(d, dy, ws[j], dx)
+            dw = torch.empty_like(ws[j])
+            d.accumulate = 0
+            conv_wgrad_raw(d, x, dy, dw)
+            grads += [dw, channel_sum(dy, N * H * W, 4 * c4, j * c4, c4)]
+        return (dx, *grads)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# InstanceNorm / BatchNorm + activation (+ residual)
+# ----------------------------------------------------------------------------------------------------------
+class InstNormActFn(torch.autograd.Function):
+    """y = act(InstanceNorm2d(x)) [+ residual], NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, residual, act):
+        lib = _lib.load()
+        x = _req(x, "norm input")
+        residual = None if residual is None else _req(residual, "norm residual")
+        N, H, W, Cn = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+        _timed("norm_act_fwd", 0, 4 * x.numel() * (3 if residual is None else 4), lambda: _lib.check(
+            lib.mstg_norm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), N, H * W, Cn, act, 0, None, None, None, None,
+                                  _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_fwd"))
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats = ctx.saved_tensors
+        dy = _req(dy, "norm grad_output")
+        N, H, W, Cn = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+            _timed("norm_act_bwd", 0, 4 * x.numel() * 5, lambda: _lib.check(
+                lib.mstg_norm_act_bwd(_p(x), _p(stats), _p(dy), _p(dx), N, H * W, Cn, ctx.act, 0, None, None, None, None,
+                                      _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
+        return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None
+
+
+def instnorm_act(x, act=ACT_RELU, residual=None):
+    return InstNormActFn.apply(x, residual, act)
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """y = act(BatchNorm2d(x)), NHWC; training mode updates running stats in place (momentum 0.1)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, act, training):
+        lib = _lib.load()
+        x, gamma, beta = _req(x, "norm input"), _req(gamma, "bn weight"), _req(beta, "bn bias")
+        N, H, W, Cn = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((1, Cn, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+        _lib.check(lib.mstg_norm_act_fwd(_p(x), None, _p(y), _p(stats), N, H * W, Cn, act, 1 if training else 2, _p(gamma),
+                                         _p(beta), _p(running_mean), _p(running_var), _p(ws), ws.numel() * 4, _stream()),
+                   "mstg_norm_act_fwd(batch)")
+        ctx.act, ctx.training = act, training
+        ctx.save_for_backward(x, stats, gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        if not ctx.training:
+            raise RuntimeError("mstg_hip: backward through eval-mode BatchNorm is not implemented")
+        x, stats, gamma, beta = ctx.saved_tensors
+        dy = _req(dy, "norm grad_output")
+        N, H, W, Cn = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(beta)
+        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+        _lib.check(lib.mstg_norm_act_bwd(_p(x), _p(stats), _p(dy), _p(dx), N, H * W, Cn, ctx.act, 1, _p(gamma), _p(beta), _p(dg),
+                                         _p(db), _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_bwd(batch)")
+        return dx, dg, db, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------
+# window attention core
+# ----------------------------------------------------------------------------------------------------------
+class WindowAttnCoreFn(torch.autograd.Function):
+    """o = attn(q^, k^) v per 4x4 window; qkv NHWC (N,H,W,3C) -> o NHWC (N,H,W,C)."""
+
+    @staticmethod
+    def forward(ctx, qkv):
+        qkv = _req(qkv, "qkv")
+        N, H, W, C3 = qkv.shape
+        Cn = C3 // 3
+        o = torch.empty((N, H, W, Cn), dtype=torch.float32, device=qkv.device)
+        cp = 16 if Cn <= 16 else (32 if Cn <= 32 else 64)
+        _timed(f"attn_core_fwd_kernel<{cp}>", 4 * Cn * Cn * N * H * W, 4 * 4 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_core_fwd(_p(qkv), _p(o), N, H, W, Cn, _stream()), "mstg_window_attn_core_fwd"))
+        ctx.save_for_backward(qkv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        do = _req(do, "attention grad_output")
+        N, H, W, C3 = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        Cn = C3 // 3
+        cp = 16 if Cn <= 16 else (32 if Cn <= 32 else 64)
+        _timed(f"attn_core_bwd_kernel<{cp}>", 12 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_core_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, _stream()), "mstg_window_attn_core_bwd"))
+        return dqkv
+
+
+# ----------------------------------------------------------------------------------------------------------
+# element-wise, losses, Adam
+# ----------------------------------------------------------------------------------------------------------
+def act_fwd_raw(x, act):
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().mstg_act_fwd(_p(x), _p(y), x.numel(), act, _stream()), "mstg_act_fwd")
+    return y
+
+
+def act_bwd_raw(x_or_y, dy, act):
+    dx = torch.empty_like(dy)
+    _lib.check(_lib.load().mstg_act_bwd(_p(x_or_y), _p(dy), _p(dx), dy.numel(), act, _stream()), "mstg_act_bwd")
+    return dx
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _req(x, "activation input")
+        y = act_fwd_raw(x, act)
+        ctx.act = act
+        ctx.save_for_backward(y if act == ACT_TANH else x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (t,) = ctx.saved_tensors
+        return act_bwd_raw(t, _req(dy, "activation grad_output"), ctx.act), None
+
+
+def activation(x, act):
+    return ActFn.apply(x, act)
+
+
+class MeanLossFn(torch.autograd.Function):
+    """mean(|a-b|) (kind LOSS_L1) or mean((a-b)^2) (kind LOSS_MSE); b may be None => constant bconst."""
+
+    @staticmethod
+    def forward(ctx, a, b, bconst, kind):
+        lib = _lib.load()
+        a = _req(a, "loss input")
+        b = None if b is None else _req(b, "loss target")
+        if b is not None and b.shape != a.shape:
+            raise RuntimeError(f"mstg_hip loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        ws = _ws(lib.mstg_loss_workspace_bytes(a.numel()), a.device)
+        _lib.check(lib.mstg_loss_mean_fwd(_p(a), _p(b), float(bconst), a.numel(), kind, _p(out), _p(ws), ws.numel() * 4, _stream()),
+                   "mstg_loss_mean_fwd")
+        ctx.kind, ctx.bconst = kind, float(bconst)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = _req(g, "loss grad_output").reshape(1)
+        need_b = b is not None and ctx.needs_input_grad[1]
+        da = torch.empty_like(a)
+        db = torch.empty_like(b) if need_b else None
+        _lib.check(_lib.load().mstg_loss_mean_bwd(_p(a), _p(b), ctx.bconst, a.numel(), ctx.kind, _p(g), 1.0, _p(da), _p(db), _stream()),
+                   "mstg_loss_mean_bwd")
+        return (da if ctx.needs_input_grad[0] else None), db, None, None
+
+
+def l1_loss(a, b):
+    return MeanLossFn.apply(a, b, 0.0, LOSS_L1)
+
+
+def mse_loss(a, b):
+    return MeanLossFn.apply(a, b, 0.0, LOSS_MSE)
+
+
+def mse_to_const(a, value: float):
+    """nn.MSELoss()(a, full_like(a, value)) -- the LSGAN targets of enhanced_train.py:72-79,100-101."""
+    return MeanLossFn.apply(a, None, float(value), LOSS_MSE)
+
+
+class SpatialMeanFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d(1) on NHWC: (N,H,W,C) -> (N,C)  (enhanced_generator.py:143,257)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "pool input")
+        N, H, W, Cn = x.shape
+        ctx.shape = (N, H, W, Cn)
+        out = torch.empty((N, Cn), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().mstg_segment_mean_fwd(_p(x), N, H * W, Cn, _p(out), _stream()), "mstg_segment_mean_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, Cn = ctx.shape
+        dy = _req(dy, "pool grad_output")
+        dx = torch.empty((N, H, W, Cn), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.load().mstg_segment_mean_bwd(_p(dy), N, H * W, Cn, _p(dx), _stream()), "mstg_segment_mean_bwd")
+        return dx
+
+
+def spatial_mean(x):
+    return SpatialMeanFn.apply(x)
+
+
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, mask=None):
+    _lib.check(_lib.load().mstg_adam_step_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step), _p(mask),
+                                               _stream()), "mstg_adam_step_flat")

@@ -65,7 +65,7 @@ def check(name, mine, ref, tol=1e-5):
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: buffers such as weight_u are updated in place later
 
 
 def clone_sd(sd):

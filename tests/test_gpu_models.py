@@ -1,0 +1,267 @@
+"""GPU parity of the drop-in modules and the training step against (a) the golden vectors produced by the
+reference's own modules and (b) the oracle run live on the CPU with the same seeded weights/inputs.
+
+Tolerance: north star = 1e-3 relative (fp32).  Forward taps are held to 1e-4, parameter gradients to 1e-3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mstg_hip import _lib
+    _lib.load()
+
+
+def report(name, err, tol):
+    print(f"  [parity] {name:60s} rel-L2 {err:.2e} (tol {tol:.0e})")
+    assert err <= tol, f"{name}: {err:.3e} > {tol:.0e}"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("tag", ["c8_32x48", "c16_64x64"])
+@pytest.mark.parametrize("checkpointing", [False, True])
+def test_generator_vs_reference_golden(gold_dir, tag, checkpointing):
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    g = np.load(os.path.join(gold_dir, f"generator_{tag}.npz"))
+    C, shape, seed = int(g["C"]), tuple(g["shape"]), int(g["seed"])
+    m = eg.EnhancedGenerator(channels=C, num_transformer_blocks=0)
+    m.load_state_dict(R.make_state_dict(R.generator_spec(C), seed))
+    m.to(DEV)
+    if checkpointing:
+        m.gradient_checkpointing_enable()
+    x = R.make_input(shape, seed + 100).to(DEV).requires_grad_(True)
+    taps = {}
+    y = m.forward_taps(x, taps)
+    for k in ("initial", "down1", "down2", "up1", "up2"):
+        report(f"G[{tag}] ckpt={int(checkpointing)} tap {k}", rel_l2(nchw(taps[k]), _t(g["tap_" + k])), 1e-4)
+    report(f"G[{tag}] pre_tanh", rel_l2(taps["pre_tanh"], _t(g["pre_tanh"])), 1e-4)
+    report(f"G[{tag}] out", rel_l2(y, _t(g["out"])), 1e-4)
+    names = [k for k, _ in m.named_parameters() if not k.startswith("style_encoder")]
+    params = [p for k, p in m.named_parameters() if not k.startswith("style_encoder")]
+    loss = y.abs().mean()
+    grads = torch.autograd.grad(loss, [x] + params)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    report(f"G[{tag}] dx", rel_l2(grads[0], _t(g["dx"])), 1e-3)
+    worst = 0.0
+    for k, gr in zip(names, grads[1:]):
+        ref = _t(g["d_" + k])
+        if k.endswith("weight"):
+            e = rel_l2(gr, ref)
+            worst = max(worst, e)
+            assert e <= 1e-3, (k, e)
+        elif float(ref.abs().max()) < 1e-5:  # bias in front of InstanceNorm: exactly-zero gradient, rounding noise
+            assert float(gr.abs().max()) < 1e-4, k
+        else:
+            assert rel_l2(gr, ref) <= 1e-3, k
+    print(f"  [parity] G[{tag}] worst weight-grad rel-L2 {worst:.2e}")
+
+
+def test_generator_no_grad_blocks1_eval_and_errors():
+    """What the inference callers do: num_transformer_blocks=1, .eval(), torch.no_grad() (direct_transform.py:35-63)."""
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    sd = R.make_state_dict(R.generator_spec(16), 7)
+    m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
+    m.load_state_dict(sd)  # identity block owns no keys -> strict load works
+    m.to(DEV).eval()
+    x = R.make_input((1, 3, 128, 128), 8)
+    with torch.no_grad():
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y = m(x.to(DEV))
+        yr = R.generator_forward(sd, x)
+    report("G blocks=1 eval 128x128 vs oracle", rel_l2(y, yr), 1e-4)
+    assert y.shape == (1, 3, 128, 128) and float(y.abs().max()) <= 1.0
+    for bad in ((1, 3, 250, 250), (1, 3, 248, 248), (1, 3, 128, 136 + 4)):
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(bad, device=DEV))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros((1, 4, 64, 64), device=DEV))
+    # two runs, same bits (fixed-order reductions everywhere)
+    with torch.no_grad():
+        y2 = m(x.to(DEV))
+    assert torch.equal(y, y2)
+
+
+def test_generator_backward_is_deterministic():
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    m = eg.EnhancedGenerator(channels=8, num_transformer_blocks=0)
+    m.load_state_dict(R.make_state_dict(R.generator_spec(8), 9))
+    m.to(DEV)
+    x = R.make_input((2, 3, 32, 32), 10).to(DEV)
+    outs = []
+    for _ in range(2):
+        grads = torch.autograd.grad(m(x).abs().mean(), list(m.parameters()), allow_unused=True)
+        outs.append([g.clone() for g in grads if g is not None])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_discriminator_vs_reference_golden(gold_dir):
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    g = np.load(os.path.join(gold_dir, "discriminator_c8_64x64.npz"))
+    C, shape, seed = int(g["C"]), tuple(g["shape"]), int(g["seed"])
+    m = eg.EnhancedDiscriminator(channels=C)
+    m.load_state_dict(R.make_state_dict(R.discriminator_spec(C), seed))
+    m.to(DEV).train()
+    x = R.make_input(shape, seed + 100).to(DEV)
+    names = [k for k, _ in m.named_parameters()]
+    for it in (1, 2):
+        xi = x.clone().requires_grad_(True)
+        s, st = m(xi)
+        loss = ((s - 1.0) ** 2).mean() + st.abs().mean()
+        grads = torch.autograd.grad(loss, [xi] + list(m.parameters()))
+        report(f"D train fwd#{it} score", rel_l2(s, _t(g[f"t{it}_score"])), 1e-4)
+        report(f"D train fwd#{it} struct", rel_l2(st, _t(g[f"t{it}_struct"])), 1e-4)
+        report(f"D train fwd#{it} dx", rel_l2(grads[0], _t(g[f"t{it}_dx"])), 1e-3)
+        for k, gr in zip(names, grads[1:]):
+            if k.endswith("weight_orig"):
+                report(f"D train fwd#{it} d{k}", rel_l2(gr, _t(g[f"t{it}_d_{k}"])), 1e-3)
+        for k, v in m.state_dict().items():
+            if k.endswith(("_u", "_v")):
+                assert rel_l2(v, _t(g[f"t{it}_{k}"])) <= 1e-5, k
+    m.eval()
+    with torch.no_grad():
+        s, st = m(x)
+        s1, _ = m(x[:1])
+    report("D eval score", rel_l2(s, _t(g["eval_score"])), 1e-4)
+    report("D eval struct", rel_l2(st, _t(g["eval_struct"])), 1e-4)
+    assert s.shape == (2,) and st.shape == (2, 1, 3, 3) and s1.dim() == 0
+
+
+def test_plain_generator_vs_reference_golden(gold_dir):
+    import plain_generator
+    from oracle import restatement as R
+    g = np.load(os.path.join(gold_dir, "plain_generator_c8_32x32.npz"))
+    C, shape, seed = int(g["C"]), tuple(g["shape"]), int(g["seed"])
+    m = plain_generator.Generator(channels=C)
+    m.load_state_dict(R.make_state_dict(R.plain_generator_spec(C), seed))
+    m.to(DEV).train()
+    x = R.make_input(shape, seed + 100).to(DEV).requires_grad_(True)
+    y = m(x)
+    names = [k for k, _ in m.named_parameters()]
+    grads = torch.autograd.grad(y.abs().mean(), [x] + list(m.parameters()))
+    report("plain G train out", rel_l2(y, _t(g["train_out"])), 1e-4)
+    report("plain G train dx", rel_l2(grads[0], _t(g["train_dx"])), 1e-3)
+    for k, gr in zip(names, grads[1:]):
+        if k.endswith("weight"):
+            report(f"plain G d{k}", rel_l2(gr, _t(g["d_" + k])), 1e-3)
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            report(f"plain G {k}", rel_l2(v, _t(g["after_" + k])), 1e-4)
+        if "num_batches" in k:
+            assert int(v) == int(g["after_" + k])
+    m.eval()
+    with torch.no_grad():
+        ye = m(x.detach())
+    report("plain G eval out", rel_l2(ye, _t(g["eval_out"])), 1e-4)
+
+
+def _build_cyclegan(C, seeds):
+    import enhanced_train
+    from oracle import restatement as R
+    model = enhanced_train.EnhancedCycleGAN(channels=C, num_transformer_blocks=0, device=DEV)
+    sds = [R.make_state_dict(R.generator_spec(C), seeds[0]), R.make_state_dict(R.generator_spec(C), seeds[1]),
+           R.make_state_dict(R.discriminator_spec(C), seeds[2]), R.make_state_dict(R.discriminator_spec(C), seeds[3])]
+    for m, sd in zip((model.G_AB, model.G_BA, model.D_A, model.D_B), sds):
+        m.load_state_dict(sd)
+    return model, sds
+
+
+def test_train_step_vs_reference_golden(gold_dir):
+    """The reference's unmodified train_step (3 steps, C=8, 64x64, batch 2) against ours.  Step 0 is a pure function
+    of the inputs (1e-4); later steps inherit Adam's +-lr sign noise on zero-gradient elements, which the reference
+    itself shows against its own restatement (oracle/make_golden.py) -- 2e-3 there."""
+    from oracle import restatement as R
+    g = np.load(os.path.join(gold_dir, "train_step_c8_64x64.npz"))
+    C, shape = int(g["C"]), tuple(g["shape"])
+    model, sds = _build_cyclegan(C, [int(s) for s in g["seeds"]])
+    keys = ("d_loss", "g_loss", "cycle_loss", "identity_loss", "structure_loss")
+    for step in range(3):
+        a, b = R.make_input(shape, 700 + 2 * step).to(DEV), R.make_input(shape, 701 + 2 * step).to(DEV)
+        out = model.train_step(a, b)
+        ref = g[f"losses_{step}"]
+        tol = 1e-4 if step == 0 else 2e-3
+        print(f"  [parity] train_step {step}: ours {[round(out[k], 6) for k in keys]}  reference {[round(float(r), 6) for r in ref]}")
+        for k, r in zip(keys, ref):
+            assert abs(out[k] - r) <= tol * max(1.0, abs(r)), (step, k, out[k], r)
+        if step == 0:
+            for name, m, sd0, lr in (("G_AB", model.G_AB, sds[0], 5e-5), ("D_A", model.D_A, sds[2], 2e-4)):
+                st = m.state_dict()
+                for k in st:
+                    if k.startswith("style_encoder"):
+                        assert torch.equal(st[k].cpu(), sd0[k]), k  # no gradient -> untouched, as with torch's Adam
+                assert rel_l2(torch.tensor(float(sum((st[k].cpu() - sd0[k]).double().pow(2).sum() for k in st)) ** 0.5),
+                              torch.tensor(float(g[f"delta_norm_0_{name}"]))) <= 2e-2
+    w = model.G_AB.state_dict()["output.0.weight"].cpu()
+    assert float((w - _t(g["final_G_AB_output.0.weight"])).abs().max()) <= 2.1 * 5e-5 * 3
+    u = model.D_A.state_dict()["main.0.weight_u"].cpu()
+    assert rel_l2(u, _t(g["final_D_A_main.0.weight_u"])) <= 1e-2
+
+
+def test_train_step_gradients_vs_oracle():
+    """First-step gradients of both optimizers against the oracle's autograd on the CPU (C=8, 32x32, batch 2) --
+    isolates the backward path from Adam's sign amplification."""
+    from oracle import restatement as R
+    C, shape = 8, (2, 3, 32, 32)
+    model, sds = _build_cyclegan(C, [81, 82, 83, 84])
+    a, b = R.make_input(shape, 90), R.make_input(shape, 91)
+    captured = {}
+    orig_d_step, orig_g_step = model.d_optimizer.step, model.g_optimizer.step
+    model.d_optimizer.step = lambda: captured.__setitem__("d", model.d_optimizer.grad.clone())
+    model.g_optimizer.step = lambda: captured.__setitem__("g", model.g_optimizer.grad.clone())
+    losses = model.train_step(a.to(DEV), b.to(DEV))
+    model.d_optimizer.step, model.g_optimizer.step = orig_d_step, orig_g_step
+    # oracle, with optimizer steps disabled the same way
+    oracle = R.CycleGANOracle(*[{k: v.clone() for k, v in sd.items()} for sd in sds])
+    og = {}
+    oracle.d_opt.step = lambda grads: og.__setitem__("d", grads)
+    oracle.g_opt.step = lambda grads: og.__setitem__("g", grads)
+    lo = oracle.train_step(a, b)
+    for k in lo:
+        assert abs(losses[k] - lo[k]) <= 1e-4 * max(1.0, abs(lo[k])), (k, losses[k], lo[k])
+
+    def flat_of(opt, grads, keys):
+        out = []
+        for (sd, k), gr in zip(keys, grads):
+            out.append(torch.zeros_like(sd[k]).flatten() if gr is None else gr.flatten())
+        return out
+
+    for which, opt, keys in (("d", model.d_optimizer, oracle.d_keys), ("g", model.g_optimizer, oracle.g_keys)):
+        ref_list = flat_of(opt, og[which], keys)
+        ours = captured[which].cpu()
+        # our flat layout follows module.parameters() order == state-dict parameter order used by the oracle
+        names = [n for m in ((model.D_A, model.D_B) if which == "d" else (model.G_AB, model.G_BA)) for n, _ in m.named_parameters()]
+        okeys = [k for _, k in keys]
+        assert names == okeys, "parameter order differs between the module and the oracle"
+        worst = 0.0
+        for off, p, ref, name in zip(opt.offsets, opt.params, ref_list, names):
+            mine = ours[off:off + p.numel()]
+            if float(ref.abs().max()) < 1e-5:
+                assert float(mine.abs().max()) < 1e-4, name
+                continue
+            e = rel_l2(mine, ref)
+            worst = max(worst, e)
+            assert e <= 1e-3, (which, name, e)
+        print(f"  [parity] train_step first-step {which}-gradients worst rel-L2 {worst:.2e}")
