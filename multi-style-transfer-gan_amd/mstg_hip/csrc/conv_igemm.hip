@@ -105,13 +105,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
                     const int ix = x0 + pc;
                     const bool inb = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (inb) {
-                        const float* src = a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_ctot + a.x_coff + chunk * CK + 4 * q;
-                        if (al) {
+                    const int c0 = chunk * CK + 4 * q;
+                    if (inb && c0 < a.Cr) {
+                        const float* src = a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_ctot + a.x_coff + c0;
+                        if (al && c0 + 3 < a.Cr) {
                             v = *reinterpret_cast<const f32x4*>(src);
                         } else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) v[c] = src[c];
+                            for (int c = 0; c < 4; ++c)
+                                if (c0 + c < a.Cr) v[c] = src[c];
                         }
                     }
                     *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * CKP + 4 * q]) = v;
@@ -248,8 +250,7 @@ int launch_igemm(IGemmArgs& a, hipStream_t st) {
         V = 1;
     } else if (a.Cr % 16 == 0) V = 4;
     else if (a.Cr % 8 == 0) V = 2;
-    else if (a.Cr % 4 == 0) V = 1;
-    else return fail_arg(MSTG_E_ALIGN, "conv: NHWC reduction channel count must be a multiple of 4");
+    else V = 1;  // any channel count: 4-channel k-slots, the tail quad zero-filled
     const int nfw = a.Co <= 16 ? 1 : (a.Co <= 32 ? 2 : 4);
 #define MSTG_DISPATCH(VV, NN) \
     if (V == VV && nfw == NN) return launch_igemm_t<VV, NN>(a, st);
