@@ -28,6 +28,7 @@ struct WGradArgs {
     int T;      // taps
     int TGn;    // taps per z-slice
     int n_gchunks;
+    int with_bias;  // also emit per-split column sums of the grid tensor (Conv2d bias gradient) after the T*Cg*Ch block
 };
 
 constexpr int WT_H = 8, WT_W = 16, G_CKP = 20;
@@ -57,6 +58,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
         for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    const bool do_bias = a.with_bias && gchunk == 0 && blockIdx.z == 0;
+    float bsum = 0.f;  // thread c < BN: running column sum of grid channel h0 + c
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int y0 = ty0 * WT_H * s - a.pad, x0 = tx0 * WT_W * s - a.pad;
@@ -133,6 +136,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
             }
         }
         __syncthreads();
+        if (do_bias && tid < BN) {
+#pragma unroll 8
+            for (int p = 0; p < 128; ++p) bsum += ht[p * BNP + tid];
+        }
         // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------
 #pragma unroll 1
         for (int rr = 0; rr < 2; ++rr) {
@@ -174,8 +181,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
         }
         __syncthreads();
     }
+    const size_t pstride = (size_t)a.T * a.Cg * a.Ch + (a.with_bias ? a.Ch : 0);
+    if (do_bias && tid < BN && h0 + tid < a.Ch) a.partial[(size_t)blockIdx.x * pstride + (size_t)a.T * a.Cg * a.Ch + h0 + tid] = bsum;
     if (wave == 0) {
-        float* out = a.partial + (size_t)blockIdx.x * a.T * a.Cg * a.Ch;
+        float* out = a.partial + (size_t)blockIdx.x * pstride;
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
             if (t >= tn) continue;
@@ -192,16 +201,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     }
 }
 
-// dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int T, int Cg, int Ch,
-                                    int s_g, int s_h) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = T * Cg * Ch;
-    if (idx >= total) return;
+// dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]  (+ dbias[hch] from the tail of each split's block).
+// A workgroup owns 16 consecutive outputs; its 16 thread-rows stride over the splits and are combined through LDS in a
+// fixed order, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int S, int T, int Cg, int Ch, int s_g,
+                                                           int s_h, int pstride) {
+    __shared__ float sh[16][17];
+    const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int total = T * Cg * Ch, nout = pstride;
+    const int idx = blockIdx.x * 16 + e;
     float sum = 0.f;
-    for (int sp = 0; sp < S; ++sp) sum += partial[(size_t)sp * total + idx];
-    const int hch = idx % Ch, gch = (idx / Ch) % Cg, t = idx / (Ch * Cg);
-    dw[(size_t)gch * s_g + (size_t)hch * s_h + t] = sum;
+    if (idx < nout)
+        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * pstride + idx];
+    sh[row][e] = sum;
+    __syncthreads();
+    if (row == 0 && idx < nout) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k][e];
+        if (idx < total) {
+            const int hch = idx % Ch, gch = (idx / Ch) % Cg, t = idx / (Ch * Cg);
+            dw[(size_t)gch * s_g + (size_t)hch * s_h + t] = r;
+        } else if (dbias) {
+            dbias[idx - total] = r;
+        }
+    }
 }
 
 struct WGradPlan {
@@ -222,7 +247,7 @@ static WGradPlan plan_wgrad(const WGradArgs& a) {
     if (S < 1) S = 1;
     if (S > a.ntiles) S = a.ntiles;
     p.S = S;
-    p.ws_bytes = (size_t)S * a.T * a.Cg * a.Ch * sizeof(float);
+    p.ws_bytes = (size_t)S * ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
     return p;
 }
 
@@ -285,13 +310,15 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d)) return rc;
     if (!x || !dy || !dw || !workspace) return fail_arg(MSTG_E_BADARG, "conv_wgrad: null pointer");
-    (void)dbias;  // bias gradients are produced by mstg_channel_sum (one more pass over dy); kept in the ABI for fusion
+    if (dbias && d->transposed)
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient only for Conv2d (use mstg_channel_sum for ConvTranspose2d)");
     WGradArgs a{};
     if (int rc = fill_wgrad_args(d, x, dy, a)) return rc;
     const WGradPlan p = plan_wgrad(a);
     if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
     a.partial = (float*)workspace;
     a.TGn = p.TGn;
+    a.with_bias = dbias != nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc = MSTG_E_UNSUPPORTED;
     if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
@@ -305,7 +332,9 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     // Conv2d: dw[co][ci][t] (gch = ci, hch = co) ; ConvTranspose2d: dw[ci][co][t] (gch = co, hch = ci)
     const int s_g = d->transposed ? T : T;
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, a.partial, dw, p.S, T, a.Cg, a.Ch, s_g, s_h);
+    const int pstride = total + (a.with_bias ? a.Ch : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, p.S, T, a.Cg, a.Ch, s_g, s_h,
+                       pstride);
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;
 }

@@ -114,12 +114,14 @@ __global__ void channel_sum_partial_kernel(const float* __restrict__ x, size_t P
     }
 }
 
+// one workgroup per channel: 256 threads stride over the partial rows, fixed-order combine
 __global__ void channel_sum_final_kernel(const float* __restrict__ partial, int nb, int C, float scale, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[8];
+    const int c = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nb; ++b) s += partial[(size_t)b * C + c];
-    out[c] = s * scale;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[(size_t)b * C + c];
+    const float r = block_sum(s, sh);
+    if (threadIdx.x == 0) out[c] = r * scale;
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
@@ -180,8 +182,8 @@ __global__ void segment_broadcast_kernel(const float* __restrict__ dy, size_t P,
 }
 
 static int channel_sum_blocks(size_t P) {
-    size_t nb = cdivz(P, 256);
-    if (nb > 512) nb = 512;
+    size_t nb = cdivz(P, 1024);
+    if (nb > 256) nb = 256;
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -251,7 +253,7 @@ extern "C" int mstg_channel_sum(const float* x, size_t P, int ctot, int coff, in
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nb), dim3(threads), threads * sizeof(float), st, x, P, ctot, coff, C, (float*)workspace);
     MSTG_CHECK_LAUNCH("channel_sum_partial_kernel");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
     MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
     return MSTG_OK;
 }
@@ -270,7 +272,7 @@ extern "C" int mstg_plane_sum(const float* x, int N, int C, size_t HW, float sca
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(plane_sum_partial_kernel, dim3(nb, C), dim3(256), 0, st, x, N, C, HW, (float*)workspace);
     MSTG_CHECK_LAUNCH("plane_sum_partial_kernel");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
     MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
     return MSTG_OK;
 }

@@ -107,7 +107,8 @@ def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
         _lib.load().mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _stream()), "mstg_conv2d_dgrad"))
 
 
-def conv_wgrad_raw(d: ConvDesc, x, dy, dw):
+def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):
+    """dw (and, for Conv2d, the bias gradient db in the same pass over dy)."""
     lib = _lib.load()
     nbytes = lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = _ws(nbytes, x.device)
@@ -116,7 +117,7 @@ def conv_wgrad_raw(d: ConvDesc, x, dy, dw):
     ch = d.Cin if d.transposed else d.Cout
     sym = f"wgrad_kernel<{1 if T == 1 else (9 if T <= 9 else 16)},{1 if ch <= 16 else 2}>"
     _timed(sym, fl, by, lambda: _lib.check(
-        lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), None, _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"))
+        lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"))
 
 
 def channel_sum(x: Tensor, P: int, ctot: int, coff: int, Cn: int, scale: float = 1.0) -> Tensor:
@@ -180,10 +181,14 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             conv_dgrad_raw(d, dy, w, dx)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            conv_wgrad_raw(d, x, dy, dw)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if fuse_db:
+                db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+            conv_wgrad_raw(d, x, dy, dw, db if fuse_db else None)
+        if want_db and not fuse_db:
             db = plane_sum_nchw(dy) if y_nchw else channel_sum(dy, N * Ho * Wo, Cout, 0, Cout)
         return dx, dw, db, None
 
@@ -226,8 +231,9 @@ class MSBranchesFn(torch.autograd.Function):
                 conv_dgrad_raw(d, dy, ws[j], dx)
             dw = torch.empty_like(ws[j])
             d.accumulate = 0
-            conv_wgrad_raw(d, x, dy, dw)
-            grads += [dw, channel_sum(dy, N * H * W, 4 * c4, j * c4, c4)]
+            db = torch.empty(c4, dtype=torch.float32, device=dy.device)
+            conv_wgrad_raw(d, x, dy, dw, db)
+            grads += [dw, db]
         return (dx, *grads)
 
 
