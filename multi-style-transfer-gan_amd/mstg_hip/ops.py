@@ -60,11 +60,11 @@ class KernelTimer:
     records = []
 
     @classmethod
-    def summary(cls):
+    def summary(cls, detail=False):
         """{symbol: dict(launches, ms, flops, bytes)} -- call after torch.cuda.synchronize()."""
         out = {}
-        for sym, s, e, fl, by in cls.records:
-            r = out.setdefault(sym, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for sym, s, e, fl, by, det in cls.records:
+            r = out.setdefault(f"{sym} {det}" if detail else sym, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             r["launches"] += 1
             r["ms"] += s.elapsed_time(e)
             r["flops"] += fl
@@ -72,14 +72,19 @@ class KernelTimer:
         return out
 
 
-def _timed(sym, flops, nbytes, fn):
+def _timed(sym, flops, nbytes, fn, detail=""):
     if not KernelTimer.enabled:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     fn()
     e.record()
-    KernelTimer.records.append((sym, s, e, float(flops), float(nbytes)))
+    KernelTimer.records.append((sym, s, e, float(flops), float(nbytes), detail))
+
+
+def _conv_detail(tag, d: ConvDesc):
+    return (f"{tag} N{d.N} {d.H}x{d.W} {d.Cin}->{d.Cout} k{d.KH} s{d.stride} d{d.dil}" + (" T" if d.transposed else "")
+            + (f" ycoff{d.y_coff}/{d.y_ctot}" if d.y_ctot != d.Cout else ""))
 
 
 def _conv_cost(d: ConvDesc):
@@ -98,13 +103,13 @@ def _igemm_symbol(cr, co, src_nchw):
 def conv_fwd_raw(d: ConvDesc, x, w, b, y):
     fl, by = _conv_cost(d)
     _timed(_igemm_symbol(d.Cin, d.Cout, d.x_nchw), fl, by, lambda: _lib.check(
-        _lib.load().mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _stream()), "mstg_conv2d_fwd"))
+        _lib.load().mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _stream()), "mstg_conv2d_fwd"), _conv_detail("fwd", d))
 
 
 def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
     fl, by = _conv_cost(d)
     _timed(_igemm_symbol(d.Cout, d.Cin, d.y_nchw), fl, by, lambda: _lib.check(
-        _lib.load().mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _stream()), "mstg_conv2d_dgrad"))
+        _lib.load().mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _stream()), "mstg_conv2d_dgrad"), _conv_detail("dgrad", d))
 
 
 def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):
@@ -117,7 +122,8 @@ def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):
     ch = d.Cin if d.transposed else d.Cout
     sym = f"wgrad_kernel<{1 if T == 1 else (9 if T <= 9 else 16)},{1 if ch <= 16 else 2}>"
     _timed(sym, fl, by, lambda: _lib.check(
-        lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"))
+        lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"),
+        _conv_detail("wgrad", d))
 
 
 def channel_sum(x: Tensor, P: int, ctot: int, coff: int, Cn: int, scale: float = 1.0) -> Tensor:
