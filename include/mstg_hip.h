@@ -58,10 +58,13 @@ typedef struct mstg_conv_desc {
     int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
 } mstg_conv_desc;
 
+/* workspace of fwd and dgrad: room for the filter re-packed into the order the kernel stages it (a few 100 KB at most) */
+size_t mstg_conv2d_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias /*nullable*/,
-                    float* y, void* stream);
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = d(loss)/d(module input), from dy = d(loss)/d(module output) */
-int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* stream);
+int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* dw (same layout as w) and dbias (nullable) ; workspace holds per-split partial sums (deterministic, no atomics) */
 size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /*nullable*/,

@@ -12,6 +12,7 @@
 // Reference sites replaced: every nn.Conv2d / nn.ConvTranspose2d forward and the dgrad half of their autograd
 // (enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,237-265; pretrain.py:65-91).
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstg {
 thread_local char g_last_error[256] = "";
@@ -34,6 +35,7 @@ struct IGemmArgs {
     int TG;                             // taps per weight-staging group
     int ntaps;
     int act, accumulate;
+    int dbg;  // ablation bits for tools/bench_conv.py (MSTG_DBG): 1 skip filter staging, 2 skip patch staging, 4 skip MFMA
 };
 
 constexpr int TILE_H = 8, TILE_W = 16;
@@ -50,10 +52,89 @@ template <> __device__ __forceinline__ float frag_get<4>(const f32x4& f, int j) 
 
 template <int V> __host__ __device__ constexpr int ckp_of() { return V == 4 ? 20 : (V == 2 ? 12 : 4); }
 
+// ---- filter pre-pack ------------------------------------------------------------------------------------------------
+// wp[cls][chunk][tap][co (padded to CoP)][ci (CK)] : exactly the order the main kernels stage into LDS, so staging is a
+// run of 16-byte copies with no index arithmetic on the filter's own (OIHW / IOHW, flipped, parity-class) layout.
+__global__ void pack_filter_kernel(const IGemmArgs a, float* __restrict__ wp, int CK, int CoP, int nchunks, int ncls) {
+    const int total = ncls * nchunks * a.ntaps * CoP * CK;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int ci = idx % CK;
+        int rest = idx / CK;
+        const int co = rest % CoP; rest /= CoP;
+        const int t = rest % a.ntaps; rest /= a.ntaps;
+        const int chunk = rest % nchunks, cls = rest / nchunks;
+        int widx;
+        if (a.phase) {
+            const int pa = cls >> 1, pb = cls & 1, u = t >> 1, v = t & 1;
+            widx = ((1 - pa) + 2 * u) * 4 + ((1 - pb) + 2 * v);
+        } else {
+            widx = a.flip ? (a.ntaps - 1 - t) : t;
+        }
+        const int cr = chunk * CK + ci;
+        wp[idx] = (co < a.Co && cr < a.Cr) ? a.w[(size_t)co * a.w_so + (size_t)cr * a.w_sr + widx] : 0.f;
+    }
+}
+
+// tap t -> LDS offset of its first pixel inside the patch
+__device__ __forceinline__ int tap_patch_offset(const IGemmArgs& a, int t, int pa, int pb, int ckp) {
+    int pro, pco;
+    if (a.phase) {
+        pro = 1 + pa - (t >> 1);
+        pco = 1 + pb - (t & 1);
+    } else {
+        pro = (t / a.KW) * a.dil;
+        pco = (t % a.KW) * a.dil;
+    }
+    return (pro * a.PW + pco) * ckp;
+}
+
+// bias, optional accumulate, activation, store of one workgroup tile
+template <int NFW>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, const f32x4 (&acc)[NFW][2], int n, int ty0, int tx0, int co0, int pa,
+                                               int pb, int wave, int i, int g) {
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        const int gy = ty0 * TILE_H + 2 * wave + pf, gx = tx0 * TILE_W + i;
+        if (gy >= a.Gh || gx >= a.Gw) continue;
+        const int oy = a.phase ? 2 * gy + pa : gy, ox = a.phase ? 2 * gx + pb : gx;
+#pragma unroll
+        for (int wf = 0; wf < NFW; ++wf) {
+            const int co = co0 + 16 * wf + 4 * g;
+            if (co >= a.Co) continue;
+            f32x4 v = acc[wf][pf];
+            if (!a.y_nchw && co + 3 < a.Co && ((a.y_ctot | a.y_coff) & 3) == 0) {
+                float* p = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + co;
+                if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
+                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(p);
+                if (a.act != MSTG_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                }
+                *reinterpret_cast<f32x4*>(p) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (co + e >= a.Co) continue;
+                    float* p = a.y_nchw ? a.y + (((size_t)n * a.y_ctot + a.y_coff + co + e) * a.Ho + oy) * a.Wo + ox
+                                        : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + co + e;
+                    float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
+                    if (a.accumulate) val += *p;
+                    *p = apply_act(val, a.act);
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
+// "light" kernel: one tile per workgroup, many workgroups per CU (small LDS, few registers) -- for layers whose MFMA
+// work per staged byte is small (1x1 convolutions, tiny filters): they are bound by memory latency/bandwidth and want
+// occupancy, not a deep per-workgroup pipeline.
 // V   : source channels per MFMA k-slot (a lane reads V consecutive channels; K chunk = 4V channels)
 // NFW : 16-channel output fragments per workgroup (BN = 16*NFW)
+// =====================================================================================================================
 template <int V, int NFW>
-__global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
+__global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, const float* __restrict__ wp, const int CoP) {
     constexpr int CK = 4 * V, CKP = ckp_of<V>(), BN = 16 * NFW;
     typedef typename Frag<V>::T frag_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -64,7 +145,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
     const int co0 = blockIdx.y * BN;
-    const int pa = blockIdx.z >> 1, pb = blockIdx.z & 1;
+    const int cls = blockIdx.z, pa = cls >> 1, pb = cls & 1;
     const int s = a.phase ? 1 : a.stride;
     const int y0 = a.phase ? ty0 * TILE_H - 1 : ty0 * TILE_H * s - a.pad;
     const int x0 = a.phase ? tx0 * TILE_W - 1 : tx0 * TILE_W * s - a.pad;
@@ -78,7 +159,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         if (chunk) __syncthreads();
-        // ---- stage the source patch (halo included, zero outside the image) -------------------------------
+        // ---- stage the source patch (halo included, zero outside the image) -------------------------------------
         if (a.x_nchw) {  // 3-channel image tensor, V == 1: channel 3 of the k-slot group is zero
             for (int pr = wave; pr < a.PH; pr += 4) {
                 const int iy = y0 + pr;
@@ -123,37 +204,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
         for (int t0 = 0; t0 < a.ntaps; t0 += a.TG) {
             __syncthreads();  // patch staged / previous tap group consumed
             const int tn = min(a.TG, a.ntaps - t0);
-            // ---- stage this tap group's filter slice as wl[tap][co][ci] ------------------------------------
-            for (int idx = tid; idx < tn * BN * CK; idx += 256) {
-                const int ci = idx % CK, rest = idx / CK;
-                const int col = rest % BN, tl = rest / BN;
-                const int t = t0 + tl;
-                int widx;
-                if (a.phase) {
-                    const int u = t >> 1, v = t & 1;
-                    widx = ((1 - pa) + 2 * u) * 4 + ((1 - pb) + 2 * v);
-                } else {
-                    widx = a.flip ? (a.ntaps - 1 - t) : t;
-                }
-                const int co = co0 + col, cr = chunk * CK + ci;
-                float val = 0.f;
-                if (co < a.Co && cr < a.Cr) val = a.w[(size_t)co * a.w_so + (size_t)cr * a.w_sr + widx];
-                wl[(tl * BN + col) * CKP + ci] = val;
+            // ---- stage this tap group's filter slice: 16-byte copies out of the packed filter ---------------------
+            const float* base = wp + ((size_t)((cls * nchunks + chunk) * a.ntaps + t0) * CoP + co0) * CK;
+            for (int e = tid; e < tn * BN * V; e += 256) {
+                const int row = e / V, q = e % V, tl = row / BN, col = row % BN;
+                *reinterpret_cast<f32x4*>(&wl[row * CKP + 4 * q]) =
+                    *reinterpret_cast<const f32x4*>(base + ((size_t)tl * CoP + col) * CK + 4 * q);
             }
             __syncthreads();
-            // ---- MFMA over the group's taps -----------------------------------------------------------------
-            int ky = t0 / a.KW, kx = t0 % a.KW;  // running tap coordinates (gather mode)
+            // ---- MFMA over the group's taps -------------------------------------------------------------------------
             for (int tl = 0; tl < tn; ++tl) {
-                const int t = t0 + tl;
-                int pro, pco;
-                if (a.phase) {
-                    pro = 1 + pa - (t >> 1);
-                    pco = 1 + pb - (t & 1);
-                } else {
-                    pro = ky * a.dil;
-                    pco = kx * a.dil;
-                    if (++kx == a.KW) { kx = 0; ++ky; }
-                }
+                const int po = tap_patch_offset(a, t0 + tl, pa, pb, CKP);
                 frag_t af[NFW], bf[2];
 #pragma unroll
                 for (int wf = 0; wf < NFW; ++wf)
@@ -161,7 +222,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
 #pragma unroll
                 for (int pf = 0; pf < 2; ++pf) {
                     const int r = 2 * wave + pf;
-                    bf[pf] = *reinterpret_cast<const frag_t*>(&patch[((r * s + pro) * a.PW + (i * s + pco)) * CKP + V * g]);
+                    bf[pf] = *reinterpret_cast<const frag_t*>(&patch[(r * s * a.PW + i * s) * CKP + po + V * g]);
                 }
 #pragma unroll
                 for (int j = 0; j < V; ++j)
@@ -173,65 +234,226 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IGemmArgs a) {
             }
         }
     }
+    igemm_epilogue<NFW>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+}
 
-    // ---- epilogue: bias, optional accumulate, activation, store ---------------------------------------------
+// =====================================================================================================================
+// "heavy" kernel: persistent workgroups with a software pipeline (issue-early / write-late).  A stage = (tile, channel
+// chunk, tap group).  While the MFMAs of stage k run, the global loads of stage k+1 (filter slice, and the source patch
+// when a new (tile, chunk) starts) are already in flight into registers; they are written to the OTHER half of the
+// double-buffered LDS after the MFMA loop, followed by the stage's single barrier.  Every prefetch load is unconditional
+// (clamped address, value zeroed at the LDS write): nothing sits between a load and its first use, so the compiler
+// issues them back to back and waits only in front of the LDS writes.
+// SRC : 0 = NHWC source, 16-byte aligned channel quads; 1 = NHWC arbitrary channel slice (scalar loads);
+//       2 = NCHW 3-channel image tensor (V == 1)
+// =====================================================================================================================
+constexpr int NPQ = 10;  // patch float4 slots per thread  (2560 >= PH*PW*V for every geometry the host admits)
+constexpr int NWQ = 5;   // filter float4 slots per thread
+
+template <int V, int NFW, int SRC>
+__global__ __launch_bounds__(256) void igemm_heavy_kernel(const IGemmArgs a, const float* __restrict__ wp, const int CoP) {
+    constexpr int CK = 4 * V, CKP = ckp_of<V>(), BN = 16 * NFW;
+    typedef typename Frag<V>::T frag_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int PSZ = (a.PH * a.PW * CKP + 3) & ~3, WSZ = a.TG * BN * CKP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int co0 = blockIdx.y * BN;
+    const int cls = blockIdx.z, pa = cls >> 1, pb = cls & 1;
+    const int s = a.phase ? 1 : a.stride;
+    const int nchunks = (a.Cr + CK - 1) / CK;
+    const int ngroups = (a.ntaps + a.TG - 1) / a.TG;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nchunks * ngroups;
+    const int npatch = a.PH * a.PW * V;
+
+    // per-thread slot descriptors (tile independent).  patch: LDS float offset, row, col, quad; unused slots read pixel 0.
+    int p_lds[NPQ], p_rc[NPQ];
 #pragma unroll
-    for (int pf = 0; pf < 2; ++pf) {
-        const int gy = ty0 * TILE_H + 2 * wave + pf, gx = tx0 * TILE_W + i;
-        if (gy >= a.Gh || gx >= a.Gw) continue;
-        const int oy = a.phase ? 2 * gy + pa : gy, ox = a.phase ? 2 * gx + pb : gx;
+    for (int j = 0; j < NPQ; ++j) {
+        const int e = tid + 256 * j;
+        const bool used = e < npatch;
+        const int ee = used ? e : 0;
+        const int pr = ee / (a.PW * V), rem = ee % (a.PW * V), pc = rem / V, q = rem % V;
+        p_lds[j] = used ? (pr * a.PW + pc) * CKP + 4 * q : -1;
+        p_rc[j] = pr | (pc << 8) | (q << 16);
+    }
+    int w_src[NWQ], w_lds[NWQ];  // filter: offset inside the stage's packed slice (tap-local), LDS float offset, or -1
 #pragma unroll
-        for (int wf = 0; wf < NFW; ++wf) {
-            const int co = co0 + 16 * wf + 4 * g;
-            if (co >= a.Co) continue;
-            f32x4 v = acc[wf][pf];
-            if (!a.y_nchw && co + 3 < a.Co && ((a.y_ctot | a.y_coff) & 3) == 0) {
-                float* p = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + co;
-                if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co);
-                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(p);
-                if (a.act != MSTG_ACT_NONE) {
+    for (int j = 0; j < NWQ; ++j) {
+        const int e = tid + 256 * j, row = e / V, q = e % V, tl = row / BN, col = row % BN;
+        const bool used = tl < a.TG;
+        w_src[j] = used ? (tl * CoP + col) * CK + 4 * q : 0;
+        w_lds[j] = used ? row * CKP + 4 * q : -1;
+    }
+
+    // two cursors over (tile sequence number, chunk, tap group): cur = stage being computed, nxt = stage being loaded
+    int c_seq = 0, c_chunk = 0, c_tg = 0, c_tx0, c_ty0, c_n;
+    int n_seq = 0, n_chunk = 0, n_tg = 0, n_tx0, n_ty0, n_n;
+    {
+        const int tile = xcd_swizzle((int)blockIdx.x, ntiles);
+        c_tx0 = n_tx0 = tile % a.tiles_x;
+        c_ty0 = n_ty0 = (tile / a.tiles_x) % a.tiles_y;
+        c_n = n_n = tile / (a.tiles_x * a.tiles_y);
+    }
+
+    f32x4 preg[NPQ], wreg[NWQ];
+
+#define IG_LOAD_STAGE()                                                                                                     \
+    {                                                                                                                       \
+        if (n_tg == 0) {                                                                                                    \
+            const int y0 = a.phase ? n_ty0 * TILE_H - 1 : n_ty0 * TILE_H * s - a.pad;                                       \
+            const int x0 = a.phase ? n_tx0 * TILE_W - 1 : n_tx0 * TILE_W * s - a.pad;                                       \
+            _Pragma("unroll") for (int j = 0; j < NPQ; ++j) {                                                               \
+                const int iy = min(max(y0 + (p_rc[j] & 255), 0), a.H - 1), ix = min(max(x0 + ((p_rc[j] >> 8) & 255), 0), a.W - 1); \
+                if (SRC == 2) {                                                                                             \
+                    const size_t cs = (size_t)a.H * a.W;                                                                    \
+                    const float* src = a.x + (((size_t)n_n * a.x_ctot + a.x_coff) * a.H + iy) * a.W + ix;                   \
+                    preg[j][0] = src[0];                                                                                    \
+                    preg[j][1] = src[(a.Cr > 1 ? 1 : 0) * cs];                                                              \
+                    preg[j][2] = src[(a.Cr > 2 ? 2 : 0) * cs];                                                              \
+                    preg[j][3] = src[(a.Cr > 3 ? 3 : 0) * cs];                                                              \
+                } else if (SRC == 0) {                                                                                      \
+                    const int c0 = min(n_chunk * CK + 4 * (p_rc[j] >> 16), a.Cr - 4);                                       \
+                    preg[j] = *reinterpret_cast<const f32x4*>(a.x + (((size_t)n_n * a.H + iy) * a.W + ix) * a.x_ctot + a.x_coff + c0); \
+                } else {                                                                                                    \
+                    const int c0 = min(n_chunk * CK + 4 * (p_rc[j] >> 16), a.Cr - 1), rem = a.Cr - 1 - c0;                  \
+                    const float* src = a.x + (((size_t)n_n * a.H + iy) * a.W + ix) * a.x_ctot + a.x_coff + c0;              \
+                    preg[j][0] = src[0];                                                                                    \
+                    preg[j][1] = src[min(1, rem)];                                                                          \
+                    preg[j][2] = src[min(2, rem)];                                                                          \
+                    preg[j][3] = src[min(3, rem)];                                                                          \
+                }                                                                                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
+        {                                                                                                                   \
+            const int t0 = n_tg * a.TG, tlast = a.ntaps - 1 - t0;                                                           \
+            const float* base = wp + ((size_t)((cls * nchunks + n_chunk) * a.ntaps + t0) * CoP + co0) * CK;                 \
+            const int lim = tlast * CoP * CK;  /* rows of taps beyond the filter are clamped to its last tap */             \
+            _Pragma("unroll") for (int j = 0; j < NWQ; ++j) {                                                               \
+                const int off = w_src[j] > lim + (CoP - 1) * CK + CK - 4 ? 0 : w_src[j];                                    \
+                wreg[j] = *reinterpret_cast<const f32x4*>(base + off);                                                      \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+
+#define IG_STORE_STAGE(KBUF)                                                                                                \
+    {                                                                                                                       \
+        if (n_tg == 0) {                                                                                                    \
+            float* patch = smem + ((n_seq * nchunks + n_chunk) & 1) * PSZ;                                                  \
+            const int y0 = a.phase ? n_ty0 * TILE_H - 1 : n_ty0 * TILE_H * s - a.pad;                                       \
+            const int x0 = a.phase ? n_tx0 * TILE_W - 1 : n_tx0 * TILE_W * s - a.pad;                                       \
+            _Pragma("unroll") for (int j = 0; j < NPQ; ++j) {                                                               \
+                if (p_lds[j] >= 0) {                                                                                        \
+                    const int iy = y0 + (p_rc[j] & 255), ix = x0 + ((p_rc[j] >> 8) & 255);                                  \
+                    const bool inb = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;                          \
+                    const int c0 = SRC == 2 ? 0 : n_chunk * CK + 4 * (p_rc[j] >> 16);                                       \
+                    const int nreal = inb ? a.Cr - c0 : 0;                                                                  \
+                    f32x4 v = preg[j];                                                                                      \
+                    v[0] = nreal > 0 ? v[0] : 0.f;                                                                          \
+                    v[1] = nreal > 1 ? v[1] : 0.f;                                                                          \
+                    v[2] = nreal > 2 ? v[2] : 0.f;                                                                          \
+                    v[3] = nreal > 3 ? v[3] : 0.f;                                                                          \
+                    *reinterpret_cast<f32x4*>(&patch[p_lds[j]]) = v;                                                        \
+                }                                                                                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
+        {                                                                                                                   \
+            float* wl = smem + 2 * PSZ + (KBUF)*WSZ;                                                                        \
+            const int tn = min(a.TG, a.ntaps - n_tg * a.TG);                                                                \
+            _Pragma("unroll") for (int j = 0; j < NWQ; ++j) {                                                               \
+                if (w_lds[j] >= 0 && w_lds[j] < tn * BN * CKP) *reinterpret_cast<f32x4*>(&wl[w_lds[j]]) = wreg[j];          \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+
+#define IG_ADVANCE(P)                                                                                                       \
+    {                                                                                                                       \
+        if (++P##_tg == ngroups) {                                                                                          \
+            P##_tg = 0;                                                                                                     \
+            if (++P##_chunk == nchunks) {                                                                                   \
+                P##_chunk = 0;                                                                                              \
+                ++P##_seq;                                                                                                  \
+                if (P##_seq < my_tiles) {                                                                                   \
+                    const int tile = xcd_swizzle((int)blockIdx.x + P##_seq * (int)gridDim.x, ntiles);                       \
+                    P##_tx0 = tile % a.tiles_x;                                                                             \
+                    P##_ty0 = (tile / a.tiles_x) % a.tiles_y;                                                               \
+                    P##_n = tile / (a.tiles_x * a.tiles_y);                                                                 \
+                }                                                                                                           \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+
+    if (total > 0) {
+        IG_LOAD_STAGE();
+        IG_STORE_STAGE(0);
+        IG_ADVANCE(n);
+    }
+    __syncthreads();
+
+    f32x4 acc[NFW][2];
+    for (int k = 0; k < total; ++k) {
+        const bool more = k + 1 < total;
+        if (more) IG_LOAD_STAGE();  // in flight during the MFMAs below
+        const float* wl = smem + 2 * PSZ + (k & 1) * WSZ;
+        const float* patch = smem + ((c_seq * nchunks + c_chunk) & 1) * PSZ;
+        if (c_chunk == 0 && c_tg == 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
-                }
-                *reinterpret_cast<f32x4*>(p) = v;
-            } else {
+            for (int wf = 0; wf < NFW; ++wf)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (co + e >= a.Co) continue;
-                    float* p = a.y_nchw
-                                   ? a.y + (((size_t)n * a.y_ctot + a.y_coff + co + e) * a.Ho + oy) * a.Wo + ox
-                                   : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + co + e;
-                    float val = v[e] + (a.bias ? a.bias[co + e] : 0.f);
-                    if (a.accumulate) val += *p;
-                    *p = apply_act(val, a.act);
-                }
-            }
+                for (int pf = 0; pf < 2; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        // ---- MFMA over the group's taps; the fragments of tap t+1 are read from LDS while tap t's MFMAs issue ------
+        const int t0 = c_tg * a.TG, tn = min(a.TG, a.ntaps - t0);
+        const int brow0 = ((2 * wave) * s * a.PW + i * s) * CKP + V * g, brow1 = brow0 + s * a.PW * CKP;
+        const int arow = i * CKP + V * g;
+        frag_t af[NFW], bf[2], afn[NFW], bfn[2];
+        {
+            const int po = tap_patch_offset(a, t0, pa, pb, CKP);
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) af[wf] = *reinterpret_cast<const frag_t*>(&wl[16 * wf * CKP + arow]);
+            bf[0] = *reinterpret_cast<const frag_t*>(&patch[brow0 + po]);
+            bf[1] = *reinterpret_cast<const frag_t*>(&patch[brow1 + po]);
+        }
+        for (int tl = 0; tl < tn; ++tl) {
+            const int tnext = min(tl + 1, tn - 1);
+            const int po = tap_patch_offset(a, t0 + tnext, pa, pb, CKP);
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) afn[wf] = *reinterpret_cast<const frag_t*>(&wl[(tnext * BN + 16 * wf) * CKP + arow]);
+            bfn[0] = *reinterpret_cast<const frag_t*>(&patch[brow0 + po]);
+            bfn[1] = *reinterpret_cast<const frag_t*>(&patch[brow1 + po]);
+#pragma unroll
+            for (int j = 0; j < V; ++j)
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+                    for (int pf = 0; pf < 2; ++pf)
+                        acc[wf][pf] = mfma16(frag_get<V>(af[wf], j), frag_get<V>(bf[pf], j), acc[wf][pf]);
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) af[wf] = afn[wf];
+            bf[0] = bfn[0];
+            bf[1] = bfn[1];
+        }
+        if (c_chunk == nchunks - 1 && c_tg == ngroups - 1) igemm_epilogue<NFW>(a, acc, c_n, c_ty0, c_tx0, co0, pa, pb, wave, i, g);
+        if (more) {
+            IG_STORE_STAGE((k + 1) & 1);
+            IG_ADVANCE(n);
+        }
+        IG_ADVANCE(c);
+        __syncthreads();
     }
+#undef IG_LOAD_STAGE
+#undef IG_STORE_STAGE
+#undef IG_ADVANCE
 }
 
-template <int V, int NFW>
-static int launch_igemm_t(IGemmArgs& a, hipStream_t st) {
-    constexpr int CKP = ckp_of<V>(), BN = 16 * NFW;
-    a.TG = W_BUDGET_FLOATS / (BN * CKP);
-    if (a.TG < 1) a.TG = 1;
-    if (a.TG > a.ntaps) a.TG = a.ntaps;
-    const size_t lds = ((size_t)((a.PH * a.PW * CKP + 3) & ~3) + (size_t)a.TG * BN * CKP) * sizeof(float);
-    if (lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv: LDS patch too large for this geometry");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<V, NFW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(igemm)");
-        attr_set = true;
-    }
-    dim3 grid(a.N * a.tiles_x * a.tiles_y, cdiv(a.Co, BN), a.phase ? 4 : 1);
-    hipLaunchKernelGGL((igemm_kernel<V, NFW>), grid, dim3(256), lds, st, a);
-    MSTG_CHECK_LAUNCH("igemm_kernel");
-    return MSTG_OK;
-}
+struct IGemmPlan {
+    int V, nfw, src, CK, CKP, BN, CoP, nchunks, ncls, TG, heavy;
+    size_t lds, ws_bytes;
+};
 
-int launch_igemm(IGemmArgs& a, hipStream_t st) {
+static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     a.tiles_x = cdiv(a.Gw, TILE_W);
     a.tiles_y = cdiv(a.Gh, TILE_H);
     if (a.phase) {
@@ -244,16 +466,113 @@ int launch_igemm(IGemmArgs& a, hipStream_t st) {
         a.ntaps = a.KH * a.KW;
     }
     if (a.N <= 0 || a.Gh <= 0 || a.Gw <= 0 || a.Co <= 0 || a.Cr <= 0) return fail_arg(MSTG_E_BADARG, "conv: empty tensor");
-    int V;
     if (a.x_nchw) {
         if (a.Cr > 4) return fail_arg(MSTG_E_UNSUPPORTED, "conv: NCHW source supports at most 4 channels");
-        V = 1;
-    } else if (a.Cr % 16 == 0) V = 4;
-    else if (a.Cr % 8 == 0) V = 2;
-    else V = 1;  // any channel count: 4-channel k-slots, the tail quad zero-filled
-    const int nfw = a.Co <= 16 ? 1 : (a.Co <= 32 ? 2 : 4);
-#define MSTG_DISPATCH(VV, NN) \
-    if (V == VV && nfw == NN) return launch_igemm_t<VV, NN>(a, st);
+        p.V = 1;
+    } else if (a.Cr % 16 == 0) p.V = 4;
+    else if (a.Cr % 8 == 0) p.V = 2;
+    else p.V = 1;  // any channel count: 4-channel k-slots, the tail quad zero-filled
+    p.src = a.x_nchw ? 2 : ((((a.x_ctot | a.x_coff | a.Cr) & 3) == 0) ? 0 : 1);
+    p.nfw = a.Co <= 16 ? 1 : (a.Co <= 32 ? 2 : 4);
+    p.CK = 4 * p.V;
+    p.CKP = p.V == 4 ? 20 : (p.V == 2 ? 12 : 4);
+    p.BN = 16 * p.nfw;
+    p.CoP = cdiv(a.Co, p.BN) * p.BN;
+    p.nchunks = cdiv(a.Cr, p.CK);
+    p.ncls = a.phase ? 4 : 1;
+    p.ws_bytes = ((size_t)p.ncls * p.nchunks * a.ntaps * p.CoP * p.CK + 64) * sizeof(float);
+    // filter slice per stage: bounded by the LDS budget (and, for the pipelined kernel, by its prefetch registers)
+    int tg = W_BUDGET_FLOATS / (p.BN * p.CKP);
+    if (tg < 1) tg = 1;
+    if (tg > a.ntaps) tg = a.ntaps;
+    int tgh = (NWQ * 256) / (p.BN * p.V);
+    if (tgh > tg) tgh = tg;
+    const size_t patch_floats = (size_t)((a.PH * a.PW * p.CKP + 3) & ~3);
+    const size_t lds_heavy = 2 * (patch_floats + (size_t)tgh * p.BN * p.CKP) * sizeof(float);
+    // heavy = enough MFMAs per stage and wave to cover the latency of the next stage's loads
+    const int mfma_per_stage = tgh * p.nfw * 2 * p.V;
+    p.heavy = tgh >= 1 && mfma_per_stage >= 64 && a.PH <= 255 && a.PW <= 255 && a.PH * a.PW * p.V <= NPQ * 256 &&
+              lds_heavy <= 160 * 1024 && !(p.src == 2 && p.V != 1) && !(p.src == 0 && a.Cr < 4);
+    // measured on MI355X: with the packed filter the high-occupancy kernel wins everywhere except on deep-channel layers
+    // with few tiles (the discriminator's 32x32 / 16x16 maps), where a workgroup has too few neighbours to hide behind
+    p.heavy = p.heavy && a.Cr >= 64 && a.N * a.tiles_x * a.tiles_y * (p.CoP / p.BN) <= 1024;
+    { const char* e = getenv("MSTG_IGEMM"); if (e && e[0] == 'l') p.heavy = 0; }
+    if (p.heavy) {
+        p.TG = a.TG = tgh;
+        p.lds = lds_heavy;
+    } else {
+        p.TG = a.TG = tg;
+        p.lds = (patch_floats + (size_t)tg * p.BN * p.CKP) * sizeof(float);
+        if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv: LDS patch too large for this geometry");
+    }
+    return MSTG_OK;
+}
+
+static int launch_pack(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
+    const int npack = p.ncls * p.nchunks * a.ntaps * p.CoP * p.CK;
+    const int nb = cdiv(npack, 256) > 256 ? 256 : cdiv(npack, 256);
+    hipLaunchKernelGGL(pack_filter_kernel, dim3(nb), dim3(256), 0, st, a, wp, p.CK, p.CoP, p.nchunks, p.ncls);
+    MSTG_CHECK_LAUNCH("pack_filter_kernel");
+    return MSTG_OK;
+}
+
+template <int V, int NFW>
+static int launch_light_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_light_kernel<V, NFW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(igemm_light)");
+        attr_set = true;
+    }
+    dim3 grid(a.N * a.tiles_x * a.tiles_y, p.CoP / p.BN, p.ncls);
+    hipLaunchKernelGGL((igemm_light_kernel<V, NFW>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_CHECK_LAUNCH("igemm_light_kernel");
+    return MSTG_OK;
+}
+
+template <int V, int NFW, int SRC>
+static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_heavy_kernel<V, NFW, SRC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(igemm_heavy)");
+        attr_set = true;
+    }
+    // persistent workgroups: as many as fit on the chip at once (LDS / register bound), a multiple of 8 so that one
+    // workgroup's tiles all fall into one XCD's contiguous run of the tile order (xcd_swizzle)
+    const int ntiles = a.N * a.tiles_x * a.tiles_y, ny = p.CoP / p.BN, nz = p.ncls;
+    const int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
+    int gx = (256 * per_cu) / (ny * nz);
+    gx = gx < 8 ? 8 : (gx & ~7);
+    if (gx > ntiles) gx = ntiles;
+    dim3 grid(gx, ny, nz);
+    hipLaunchKernelGGL((igemm_heavy_kernel<V, NFW, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_CHECK_LAUNCH("igemm_heavy_kernel");
+    return MSTG_OK;
+}
+
+size_t igemm_workspace_bytes(IGemmArgs a) {
+    IGemmPlan p;
+    if (plan_igemm(a, p)) return 0;
+    return p.ws_bytes;
+}
+
+int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    a.dbg = 0;
+    IGemmPlan p;
+    if (int rc = plan_igemm(a, p)) return rc;
+    if (!workspace || workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv: workspace too small for the packed filter");
+    float* wp = (float*)workspace;
+    if (int rc = launch_pack(a, p, wp, st)) return rc;
+#define MSTG_DISPATCH(VV, NN)                                                              \
+    if (p.V == VV && p.nfw == NN) {                                                        \
+        if (!p.heavy) return launch_light_t<VV, NN>(a, p, wp, st);                         \
+        if (p.src == 0) return launch_heavy_t<VV, NN, 0>(a, p, wp, st);                    \
+        if (p.src == 1) return launch_heavy_t<VV, NN, 1>(a, p, wp, st);                    \
+        if (VV == 1 && p.src == 2) return launch_heavy_t<1, NN, 2>(a, p, wp, st);          \
+    }
     MSTG_DISPATCH(1, 1) MSTG_DISPATCH(1, 2) MSTG_DISPATCH(1, 4)
     MSTG_DISPATCH(2, 1) MSTG_DISPATCH(2, 2) MSTG_DISPATCH(2, 4)
     MSTG_DISPATCH(4, 1) MSTG_DISPATCH(4, 2) MSTG_DISPATCH(4, 4)
@@ -286,13 +605,8 @@ int check_desc(const mstg_conv_desc* d) {
 
 using namespace mstg;
 
-extern "C" int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                               void* stream) {
-    if (int rc = check_desc(d)) return rc;
-    if (!x || !w || !y) return fail_arg(MSTG_E_BADARG, "conv_fwd: null pointer");
+static void fill_fwd_args(const mstg_conv_desc* d, IGemmArgs& a) {
     const int T = d->KH * d->KW;
-    IGemmArgs a{};
-    a.x = x; a.y = y; a.w = w; a.bias = bias;
     a.N = d->N;
     a.H = d->H; a.W = d->W; a.x_ctot = d->x_ctot; a.x_coff = d->x_coff; a.x_nchw = d->x_nchw; a.Cr = d->Cin;
     a.Ho = d->Ho; a.Wo = d->Wo; a.y_ctot = d->y_ctot; a.y_coff = d->y_coff; a.y_nchw = d->y_nchw; a.Co = d->Cout;
@@ -305,15 +619,10 @@ extern "C" int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const fl
         a.phase = 0; a.Gh = d->Ho; a.Gw = d->Wo;
         a.w_so = d->Cin * T; a.w_sr = T;   // OIHW
     }
-    return launch_igemm(a, (hipStream_t)stream);
 }
 
-extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* stream) {
-    if (int rc = check_desc(d)) return rc;
-    if (!dy || !w || !dx) return fail_arg(MSTG_E_BADARG, "conv_dgrad: null pointer");
+static int fill_dgrad_args(const mstg_conv_desc* d, IGemmArgs& a) {
     const int T = d->KH * d->KW;
-    IGemmArgs a{};
-    a.x = dy; a.y = dx; a.w = w; a.bias = nullptr;
     a.N = d->N;
     // source = module output gradient, destination = module input gradient
     a.H = d->Ho; a.W = d->Wo; a.x_ctot = d->y_ctot; a.x_coff = d->y_coff; a.x_nchw = d->y_nchw; a.Cr = d->Cout;
@@ -334,7 +643,36 @@ extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const
         a.phase = 1; a.Gh = d->Ho; a.Gw = d->Wo; a.stride = 2; a.pad = 1; a.flip = 0;
         a.w_so = T; a.w_sr = d->Cin * T;
     }
-    return launch_igemm(a, (hipStream_t)stream);
+    return MSTG_OK;
+}
+
+extern "C" size_t mstg_conv2d_workspace_bytes(const mstg_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    IGemmArgs f{}, b{};
+    fill_fwd_args(d, f);
+    if (fill_dgrad_args(d, b)) return 0;
+    const size_t wf = igemm_workspace_bytes(f), wb = igemm_workspace_bytes(b);
+    return wf > wb ? wf : wb;
+}
+
+extern "C" int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    if (!x || !w || !y) return fail_arg(MSTG_E_BADARG, "conv_fwd: null pointer");
+    IGemmArgs a{};
+    fill_fwd_args(d, a);
+    a.x = x; a.y = y; a.w = w; a.bias = bias;
+    return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    if (!dy || !w || !dx) return fail_arg(MSTG_E_BADARG, "conv_dgrad: null pointer");
+    IGemmArgs a{};
+    if (int rc = fill_dgrad_args(d, a)) return rc;
+    a.x = dy; a.y = dx; a.w = w; a.bias = nullptr;
+    return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" const char* mstg_version(void) { return "mstg-hip 0.1.0 gfx950"; }

@@ -12,6 +12,7 @@
 // Reference sites replaced: the wgrad half of convolution_backward for every conv on the path
 // (enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,237-265; pretrain.py:65-91).
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstg {
 
@@ -28,6 +29,7 @@ struct WGradArgs {
     int T;      // taps
     int TGn;    // taps per z-slice
     int n_gchunks;
+    int dbg;        // ablation bits (MSTG_DBG): 2 skip staging, 4 skip MFMA
     int with_bias;  // also emit per-split column sums of the grid tensor (Conv2d bias gradient) after the T*Cg*Ch block
 };
 
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
         const int y0 = ty0 * WT_H * s - a.pad, x0 = tx0 * WT_W * s - a.pad;
         __syncthreads();
         // ---- stage gathered patch: 16 channels [g0, g0+16), zero beyond Cg and outside the image -------------
-        if (a.g_nchw) {
+        if (a.dbg & 2) {
+        } else if (a.g_nchw) {
             for (int pr = wave; pr < a.PH; pr += 4) {
                 const int iy = y0 + pr;
                 for (int pc = lane; pc < a.PW; pc += 64) {
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
             }
         }
         // ---- stage the grid tensor tile: 128 pixels x BN channels, zero outside ------------------------------
-        if (a.h_nchw) {
+        if (a.dbg & 2) {
+        } else if (a.h_nchw) {
             for (int c = wave; c < BN; c += 4) {
                 for (int p = lane; p < 128; p += 64) {
                     const int gy = ty0 * WT_H + (p >> 4), gx = tx0 * WT_W + (p & 15);
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
         }
         // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------
 #pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
+        for (int rr = 0; rr < ((a.dbg & 4) ? 0 : 2); ++rr) {
             const int r = 2 * wave + rr;
 #pragma unroll 1
             for (int xs = 0; xs < 4; ++xs) {
@@ -319,6 +323,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     a.partial = (float*)workspace;
     a.TGn = p.TGn;
     a.with_bias = dbias != nullptr;
+    { const char* e = getenv("MSTG_DBG"); a.dbg = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     int rc = MSTG_E_UNSUPPORTED;
     if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);

@@ -102,14 +102,20 @@ def _igemm_symbol(cr, co, src_nchw):
 
 def conv_fwd_raw(d: ConvDesc, x, w, b, y):
     fl, by = _conv_cost(d)
+    lib = _lib.load()
+    ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
     _timed(_igemm_symbol(d.Cin, d.Cout, d.x_nchw), fl, by, lambda: _lib.check(
-        _lib.load().mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _stream()), "mstg_conv2d_fwd"), _conv_detail("fwd", d))
+        lib.mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_fwd"),
+        _conv_detail("fwd", d))
 
 
 def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
     fl, by = _conv_cost(d)
+    lib = _lib.load()
+    ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
     _timed(_igemm_symbol(d.Cout, d.Cin, d.y_nchw), fl, by, lambda: _lib.check(
-        _lib.load().mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _stream()), "mstg_conv2d_dgrad"), _conv_detail("dgrad", d))
+        lib.mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_dgrad"),
+        _conv_detail("dgrad", d))
 
 
 def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):

@@ -42,12 +42,13 @@ def test_conv_desc_layout():
 def test_host_side_validation(lib):
     from mstg_hip import ops
     d = ops.make_desc(1, 16, 16, 16, 16, 16, 8, 3, 1, 1, 1)
-    assert lib.mstg_conv2d_fwd(C.byref(d), None, None, None, None, None) == -1          # null pointers
+    assert lib.mstg_conv2d_fwd(C.byref(d), None, None, None, None, None, 0, None) == -1  # null pointers
+    assert lib.mstg_conv2d_workspace_bytes(C.byref(d)) >= 9 * 16 * 16 * 4
     d = ops.make_desc(1, 16, 16, 16, 15, 16, 8, 3, 1, 1, 1)                               # wrong Ho
-    assert lib.mstg_conv2d_fwd(C.byref(d), 1, 1, None, 1, None) == -1
+    assert lib.mstg_conv2d_fwd(C.byref(d), 1, 1, None, 1, None, 0, None) == -1
     assert b"Ho" in lib.mstg_last_error()
     d = ops.make_desc(1, 16, 16, 16, 8, 8, 8, 3, 2, 1, 1)                                 # stride-2 3x3: not on the path
-    assert lib.mstg_conv2d_fwd(C.byref(d), 1, 1, None, 1, None) == -5
+    assert lib.mstg_conv2d_fwd(C.byref(d), 1, 1, None, 1, None, 0, None) == -5
     d = ops.make_desc(1, 16, 16, 16, 32, 32, 8, 4, 2, 1, 1, transposed=1)
     assert lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d)) > 0
     assert lib.mstg_window_attn_core_fwd(1, 1, 1, 6, 8, 16, None) == -1                   # H not a multiple of 4
