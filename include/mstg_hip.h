@@ -100,6 +100,18 @@ int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int H, int W, i
 /* dqkv from d_o; the attention matrix is recomputed from qkv, nothing but qkv is saved by the forward */
 int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C, void* stream);
 
+/* Fully fused LocalAttention for C = 16 and 32 (enhanced_generator.py:13-47 in one kernel per direction): the qkv and proj
+ * 1x1 convolutions (:28, :36) and the window attention between them; x is read once, y written once.  wqkv (3C,C) and
+ * wproj (C,C) are the 1x1 conv weights exactly as stored (OIHW with 1x1 taps).  The backward returns dx and ONE flat
+ * gradient vector dparams = [dWqkv (3C*C) | dWproj (C*C) | dbqkv (3C) | dbproj (C)]. */
+int mstg_window_attn_fused_supported(int C);
+int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
+                         float* y, int N, int H, int W, int C, void* stream);
+size_t mstg_window_attn_bwd_workspace_bytes(int N, int H, int W, int C);
+int mstg_window_attn_bwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
+                         const float* dy, float* dx, float* dparams, int N, int H, int W, int C, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Element-wise / reduction helpers of the training step (enhanced_train.py:49-52,72-115,36-43).
  * ---------------------------------------------------------------------------------------------- */

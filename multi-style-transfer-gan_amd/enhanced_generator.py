@@ -18,6 +18,8 @@ EnhancedGenerator :86-228, EnhancedDiscriminator :230-274.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.utils.checkpoint
@@ -45,6 +47,9 @@ class LocalAttention(nn.Module):
             raise RuntimeError(f"LocalAttention: H and W must be multiples of window_size={ws}, got {H}x{W}")
         if ws != 4:
             raise RuntimeError("LocalAttention: the HIP kernel implements window_size=4 (the only value the reference uses)")
+        if ops.fused_attention_supported(x.shape[3]) and os.environ.get("MSTG_ATTN_UNFUSED") != "1":
+            # qkv conv + window attention + proj conv in one kernel: x read once, y written once
+            return ops.LocalAttentionFusedFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias)
         qkv = self.qkv(x, nhwc=True)
         o = ops.WindowAttnCoreFn.apply(qkv)
         return self.proj(o, nhwc=True)

@@ -279,6 +279,267 @@ __global__ __launch_bounds__(64) void attn_core_bwd_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================================
+// Fully fused LocalAttention (C = 16 or 32): qkv 1x1 conv + window attention + proj 1x1 conv in ONE kernel per direction.
+// x is read once and y written once (2C floats per pixel instead of the 9C of the unfused chain); q/k/v, the C x C
+// attention matrix and o never leave the CU.  The 1x1-conv weights live in LDS for the whole (persistent) wave; in the
+// backward their gradients are accumulated in MFMA accumulators across all windows a wave processes and reduced over
+// waves by a fixed-order second kernel.
+// =====================================================================================================================
+template <int C>
+struct FusedTiles {
+    typedef AttnTiles<C> T;  // QKV, P, INVN first: attn_forward_tiles() works on them unchanged
+    static constexpr int NF = C / 16, LDX = C + 4;
+    static constexpr int XS = T::INVN + 32, OS = XS + 16 * LDX, END_FWD = OS + 16 * LDX;
+    // backward: dY and dO are dead before the first element of dQKV is written, so dQKV overlays them
+    static constexpr int DYS = END_FWD, DOS = DYS + 16 * LDX, DQKV = END_FWD;
+    static constexpr int END_BWD = END_FWD + (16 * T::LDQ > 32 * LDX ? 16 * T::LDQ : 32 * LDX);
+    static constexpr int SLAB = 4 * C * C + 4 * C;  // dWqkv | dWp | dbqkv | dbp
+};
+
+// x window -> Xs ; qkv = x Wqkv^T + b -> QKV tile ; q^,k^,P (attn_forward_tiles) ; O -> Os.  Ends with the tiles ready.
+template <int C>
+__device__ __forceinline__ void fused_forward_tiles(float* sm, const float* __restrict__ x, const float* __restrict__ wqkv,
+                                                    const float* __restrict__ bqkv, int H, int W, int n, int wy, int wx, int lane) {
+    typedef FusedTiles<C> F;
+    typedef AttnTiles<C> T;
+    constexpr int NF = F::NF;
+    const int i = lane & 15, g = lane >> 4;
+    load_window<C>(x, sm + F::XS, F::LDX, 1, C, H, W, n, wy, wx, lane);
+    WAVE_SYNC();
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+        f32x4 acc[1][NF];
+        tile_zero<1, NF>(acc);
+        // A = X (pixel x ci), B(k = ci, n = j) = Wqkv[j][ci]
+        tile_mma<1, NF>(acc, sm + F::XS, F::LDX, 1, wqkv + blk * C * C, 1, C, C, lane);  // filter straight from L1/L2
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            const float b = bqkv[blk * C + 16 * nf + i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[T::QKV + (4 * g + r) * T::LDQ + blk * C + 16 * nf + i] = acc[0][nf][r] + b;
+        }
+    }
+    WAVE_SYNC();
+    attn_forward_tiles<C>(sm, C, lane);
+    // O^T[c1][p] = sum_c2 P[c1][c2] V[p][c2], stored as Os[p][c1]
+    f32x4 o[NF][1];
+    tile_zero<NF, 1>(o);
+    tile_mma<NF, 1>(o, sm + T::P, T::LDP, 1, sm + T::QKV + 2 * C, 1, T::LDQ, C, lane);
+    tile_store<NF, 1>(o, sm + F::OS, 1, F::LDX, lane);
+    WAVE_SYNC();
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void attn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wqkv,
+                                                            const float* __restrict__ bqkv, const float* __restrict__ wp,
+                                                            const float* __restrict__ bp, float* __restrict__ y, int N, int H, int W) {
+    typedef FusedTiles<C> F;
+    constexpr int NF = F::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        fused_forward_tiles<C>(sm, x, wqkv, bqkv, H, W, n, wy, wx, lane);
+        // Y^T[co][p] = sum_c Wp[co][c] O[p][c] + b : rows = channels -> one 16-byte store per lane and fragment
+        f32x4 yv[NF][1];
+        tile_zero<NF, 1>(yv);
+        tile_mma<NF, 1>(yv, wp, C, 1, sm + F::OS, 1, F::LDX, C, lane);
+        const int py = 4 * wy + (i >> 2), px = 4 * wx + (i & 3);
+        float* dst = y + (((size_t)n * H + py) * W + px) * C;
+#pragma unroll
+        for (int mf = 0; mf < NF; ++mf) {
+            const int c = 16 * mf + 4 * g;
+            *reinterpret_cast<f32x4*>(dst + c) = yv[mf][0] + *reinterpret_cast<const f32x4*>(bp + c);
+        }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wqkv,
+                                                            const float* __restrict__ bqkv, const float* __restrict__ wp,
+                                                            const float* __restrict__ bp, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, float* __restrict__ partial, int N, int H, int W) {
+    typedef FusedTiles<C> F;
+    typedef AttnTiles<C> T;
+    constexpr int NF = F::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    float* qkv = sm + T::QKV;
+    float* Ps = sm + T::P;
+    float* invn = sm + T::INVN;
+    float* dYs = sm + F::DYS;
+    float* dOs = sm + F::DOS;
+    float* dQKV = sm + F::DQKV;
+
+    // weight-gradient accumulators, alive across every window this wave processes
+    f32x4 gwq[3][NF][NF], gwp[NF][NF];
+    float gbq[3][NF], gbp[NF];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        tile_zero<NF, NF>(gwq[b]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) gbq[b][nf] = 0.f;
+    }
+    tile_zero<NF, NF>(gwp);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) gbp[nf] = 0.f;
+
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        load_window<C>(dy, dYs, F::LDX, 1, C, H, W, n, wy, wx, lane);
+        fused_forward_tiles<C>(sm, x, wqkv, bqkv, H, W, n, wy, wx, lane);  // Xs, q^, k^, v, P, inverse norms, Os
+
+        // ---- proj backward: dO = dY Wp ; dWp += dY^T O ; dbp += colsum(dY) --------------------------------------------
+        {
+            f32x4 d[1][NF];
+            tile_zero<1, NF>(d);
+            tile_mma<1, NF>(d, dYs, F::LDX, 1, wp, C, 1, C, lane);  // B(k = co, n = c) = Wp[co][c]
+            tile_store<1, NF>(d, dOs, F::LDX, 1, lane);
+            tile_mma<NF, NF>(gwp, dYs, 1, F::LDX, sm + F::OS, F::LDX, 1, 16, lane);  // A = dY^T (co x p), B = O (p x c)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gbp[nf] += dYs[(4 * g + r) * F::LDX + 16 * nf + i];
+        }
+        WAVE_SYNC();
+        // ---- attention core backward (same algebra as attn_core_bwd_kernel), results into the dQKV tile -------------------
+        f32x4 ds[NF][NF];
+        tile_zero<NF, NF>(ds);
+        tile_mma<NF, NF>(ds, dOs, 1, F::LDX, qkv + 2 * C, T::LDQ, 1, 16, lane);  // dP[c1][c2] = sum_p dO[p][c1] V[p][c2]
+#pragma unroll
+        for (int mf = 0; mf < NF; ++mf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr[NF], dot = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    pr[nf] = Ps[(16 * mf + 4 * g + r) * T::LDP + 16 * nf + i];
+                    dot += pr[nf] * ds[mf][nf][r];
+                }
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) ds[mf][nf][r] = pr[nf] * (ds[mf][nf][r] - dot);
+            }
+        }
+        {
+            f32x4 dv[1][NF];  // dV[p][c2] = sum_c1 dO[p][c1] P[c1][c2]
+            tile_zero<1, NF>(dv);
+            tile_mma<1, NF>(dv, dOs, F::LDX, 1, Ps, T::LDP, 1, C, lane);
+            tile_store<1, NF>(dv, dQKV + 2 * C, T::LDQ, 1, lane);
+        }
+        WAVE_SYNC();
+        tile_store<NF, NF>(ds, Ps, T::LDP, 1, lane);  // P <- dS
+        WAVE_SYNC();
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            f32x4 d[1][NF];
+            tile_zero<1, NF>(d);
+            if (which == 0) tile_mma<1, NF>(d, qkv + C, T::LDQ, 1, Ps, 1, T::LDP, C, lane);  // dq^ = k^ dS^T
+            else tile_mma<1, NF>(d, qkv, T::LDQ, 1, Ps, T::LDP, 1, C, lane);                 // dk^ = q^ dS
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 4 * g + r;
+                float hat[NF], dot = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) {
+                    hat[nf] = qkv[p * T::LDQ + which * C + 16 * nf + i];
+                    dot += hat[nf] * d[0][nf][r];
+                }
+                dot = row16_sum(dot);
+                const float inv = invn[which * 16 + p];
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) dQKV[p * T::LDQ + which * C + 16 * nf + i] = (d[0][nf][r] - hat[nf] * dot) * inv;
+            }
+        }
+        WAVE_SYNC();
+        // ---- qkv conv backward: dX = dQKV Wqkv ; dWqkv += dQKV^T X ; dbqkv += colsum(dQKV) --------------------------------
+        {
+            f32x4 d[NF][1];  // dX^T[ci][p] = sum_j Wqkv[j][ci] dQKV[p][j]
+            tile_zero<NF, 1>(d);
+            tile_mma<NF, 1>(d, wqkv, 1, C, dQKV, 1, T::LDQ, 3 * C, lane);
+            const int py = 4 * wy + (i >> 2), px = 4 * wx + (i & 3);
+            float* dst = dx + (((size_t)n * H + py) * W + px) * C;
+#pragma unroll
+            for (int mf = 0; mf < NF; ++mf) *reinterpret_cast<f32x4*>(dst + 16 * mf + 4 * g) = d[mf][0];
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            tile_mma<NF, NF>(gwq[b], dQKV + b * C, 1, T::LDQ, sm + F::XS, F::LDX, 1, 16, lane);  // A = dQKV_b^T (j x p), B = X (p x ci)
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gbq[b][nf] += dQKV[(4 * g + r) * T::LDQ + b * C + 16 * nf + i];
+        }
+    }
+    // ---- this wave's slab: dWqkv (3C x C) | dWp (C x C) | dbqkv (3C) | dbp (C) ---------------------------------------------
+    float* out = partial + (size_t)blockIdx.x * F::SLAB;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) tile_store<NF, NF>(gwq[b], out + b * C * C, C, 1, lane);
+    tile_store<NF, NF>(gwp, out + 3 * C * C, C, 1, lane);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            float v = gbq[b][nf];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0) out[4 * C * C + b * C + 16 * nf + i] = v;
+        }
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+        float v = gbp[nf];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (g == 0) out[4 * C * C + 3 * C + 16 * nf + i] = v;
+    }
+}
+
+// out[e] = sum_s partial[s][e], fixed order; 16 outputs x 16 strided rows per workgroup
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, int n) {
+    __shared__ float sh[16][17];
+    const int e = threadIdx.x & 15, row = threadIdx.x >> 4, idx = blockIdx.x * 16 + e;
+    float sum = 0.f;
+    if (idx < n)
+        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * n + idx];
+    sh[row][e] = sum;
+    __syncthreads();
+    if (row == 0 && idx < n) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r += sh[k][e];
+        out[idx] = r;
+    }
+}
+
+static int fused_blocks(int N, int H, int W) {
+    const int nwin = N * (H / 4) * (W / 4);
+    return nwin < 2048 ? nwin : 2048;  // one-wave workgroups: 8 per CU
+}
+
+template <int C>
+static int launch_fused(bool bwd, const float* x, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
+                        const float* dy, float* out, float* grads, float* partial, int N, int H, int W, hipStream_t st) {
+    typedef FusedTiles<C> F;
+    const int nb = fused_blocks(N, H, W);
+    if (!bwd) {
+        hipLaunchKernelGGL((attn_fused_fwd_kernel<C>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, out,
+                           N, H, W);
+        MSTG_CHECK_LAUNCH("attn_fused_fwd_kernel");
+        return MSTG_OK;
+    }
+    hipLaunchKernelGGL((attn_fused_bwd_kernel<C>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy, out,
+                       partial, N, H, W);
+    MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB);
+    MSTG_CHECK_LAUNCH("slab_reduce_kernel");
+    return MSTG_OK;
+}
+
 static int attn_check(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "window_attn: empty tensor");
     if (H % 4 || W % 4) return fail_arg(MSTG_E_BADARG, "window_attn: H and W must be multiples of the 4x4 window");
@@ -331,4 +592,34 @@ extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, flo
     if (C <= 16) return launch_attn<16>(true, qkv, d_o, dqkv, N, H, W, C, st);
     if (C <= 32) return launch_attn<32>(true, qkv, d_o, dqkv, N, H, W, C, st);
     return launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
+}
+
+extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32; }
+
+extern "C" int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
+                                    float* y, int N, int H, int W, int C, void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!x || !wqkv || !bqkv || !wproj || !bproj || !y) return fail_arg(MSTG_E_BADARG, "window_attn_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return launch_fused<16>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
+    if (C == 32) return launch_fused<32>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
+    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_fwd: fused kernel exists for C = 16 and 32 (use the qkv/core/proj chain otherwise)");
+}
+
+extern "C" size_t mstg_window_attn_bwd_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32)) return 0;
+    return (size_t)fused_blocks(N, H, W) * (4 * C * C + 4 * C) * sizeof(float);
+}
+
+extern "C" int mstg_window_attn_bwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
+                                    const float* dy, float* dx, float* dparams, int N, int H, int W, int C, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!x || !wqkv || !bqkv || !wproj || !bproj || !dy || !dx || !dparams || !workspace)
+        return fail_arg(MSTG_E_BADARG, "window_attn_bwd: null pointer");
+    if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_bwd: fused kernel exists for C = 16 and 32");
+    if (workspace_bytes < mstg_window_attn_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return launch_fused<16>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
+    return launch_fused<32>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
 }

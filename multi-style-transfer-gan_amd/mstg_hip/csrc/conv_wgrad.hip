@@ -9,6 +9,17 @@
 // split the tile rows, are summed through LDS once at the end, and the per-workgroup partials are reduced by a
 // second tiny kernel in a fixed order (bit-reproducible: no atomics).
 //
+// Three operand packings keep the 16x16 MFMA tile full when a tensor has only 3-4 channels (the RGB image at the stem,
+// the RGB gradient at the head), where a plain channel mapping would leave 13 of 16 rows or columns idle:
+//   MODE_PLAIN : M = 16 gathered channels, N = 16 grid channels.
+//   MODE_PACKX : gathered tensor has <= 4 channels.  The LDS patch is stored [row][col][4] with no padding, so the 16
+//                floats starting at a pixel are (4 consecutive pixels) x (4 channels): M row m = 4*kx_low + c.  One MFMA
+//                covers four horizontally adjacent taps; a 7x7 filter needs 7 x 2 "taps" instead of 49.
+//   MODE_DPACK : grid tensor has <= 4 channels (stride 1, dilation 1).  The grid tile is stored [row][col][4] with three
+//                extra columns, and N column n = 4*delta + co is the gradient of the pixel delta columns to the right:
+//                D[ci][(delta,co)] accumulates x[p + tap] * dy[p + delta] = the gradient of tap (kx - delta).  The walked
+//                grid starts three columns left of the image so every (pixel, delta) pair is visited exactly once.
+//
 // Reference sites replaced: the wgrad half of convolution_backward for every conv on the path
 // (enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,237-265; pretrain.py:65-91).
 #include "common.h"
@@ -16,46 +27,58 @@
 
 namespace mstg {
 
+enum { MODE_PLAIN = 0, MODE_PACKX = 1, MODE_DPACK = 2 };
+
 struct WGradArgs {
     const float* g;   // gathered tensor
     const float* h;   // grid tensor
-    float* partial;   // [S][T][Cg][Ch]
+    float* partial;   // [S][T][Cg][Ch] (+ [Ch] bias tail)
     int N;
     int gH, gW, g_ctot, g_coff, g_nchw, Cg;
     int hH, hW, h_ctot, h_coff, h_nchw, Ch;  // hH x hW is the walked grid
     int KH, KW, stride, pad, dil;
     int tiles_x, tiles_y, ntiles;
-    int PH, PW;
-    int T;      // taps
-    int TGn;    // taps per z-slice
+    int PH, PW;     // gathered patch extent
+    int T;          // real taps KH*KW
+    int Teff;       // accumulator "taps": T, or KH * ceil(KW/4) in the packed modes
+    int tapsx;      // ceil(KW/4) in the packed modes
+    int TGn;        // accumulator taps per z-slice
     int n_gchunks;
-    int dbg;        // ablation bits (MSTG_DBG): 2 skip staging, 4 skip MFMA
+    int mode;
+    int ckp;        // LDS floats per patch pixel (20 plain/dpack: 16 channels + pad; 4 packx)
+    int htw;        // LDS grid-tile row length in pixels (16, or 20 for dpack)
+    int xshift;     // walked-grid column offset (3 for dpack, else 0)
     int with_bias;  // also emit per-split column sums of the grid tensor (Conv2d bias gradient) after the T*Cg*Ch block
 };
 
-constexpr int WT_H = 8, WT_W = 16, G_CKP = 20;
+constexpr int WT_H = 8, WT_W = 16;
 
 // TG  : accumulator fragments (taps) per workgroup z-slice;  NFH : 16-wide grid-channel fragments per workgroup
 template <int TG, int NFH>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     constexpr int BN = 16 * NFH, BNP = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                        // [PH][PW][G_CKP]
-    float* ht = smem + ((a.PH * a.PW * G_CKP + 3) & ~3);        // [128][BNP]
+    float* patch = smem;                                        // [PH][PW][ckp]
+    float* ht = smem + ((a.PH * a.PW * a.ckp + 3) & ~3);        // plain/packx: [128][BNP]; dpack: [8][htw][4]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int gchunk = blockIdx.y % a.n_gchunks, htile = blockIdx.y / a.n_gchunks;
     const int g0 = gchunk * 16, h0 = htile * BN;
     const int t0 = blockIdx.z * a.TGn;
-    const int tn = min(a.TGn, a.T - t0);
-    const int s = a.stride;
+    const int tn = min(a.TGn, a.Teff - t0);
+    const int s = a.stride, ckp = a.ckp;
+    const int mode = a.mode;
 
     f32x4 acc[TG][NFH];
-    int toff[TG];  // LDS offset of each tap inside the patch (wave-uniform, hoisted out of the pixel loops)
+    int toff[TG];  // LDS offset of each (packed) tap inside the patch (wave-uniform, hoisted out of the pixel loops)
 #pragma unroll
     for (int t = 0; t < TG; ++t) {
-        const int tt = min(t0 + t, a.T - 1);
-        toff[t] = (((tt / a.KW) * a.dil) * a.PW + (tt % a.KW) * a.dil) * G_CKP;
+        const int tt = min(t0 + t, a.Teff - 1);
+        int ky, kxo;
+        if (mode == MODE_PLAIN) { ky = tt / a.KW; kxo = (tt % a.KW) * a.dil; }
+        else if (mode == MODE_PACKX) { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx); }
+        else { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx) + 3; }
+        toff[t] = (ky * a.dil * a.PW + kxo) * ckp;
 #pragma unroll
         for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -64,17 +87,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     float bsum = 0.f;  // thread c < BN: running column sum of grid channel h0 + c
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
-        const int y0 = ty0 * WT_H * s - a.pad, x0 = tx0 * WT_W * s - a.pad;
+        const int gx0 = tx0 * WT_W - a.xshift;  // first walked-grid column of this tile
+        const int y0 = ty0 * WT_H * s - a.pad, x0 = gx0 * s - a.pad;
         __syncthreads();
-        // ---- stage gathered patch: 16 channels [g0, g0+16), zero beyond Cg and outside the image -------------
-        if (a.dbg & 2) {
+        // ---- stage the gathered patch, zero beyond Cg and outside the image -----------------------------------
+        if (mode == MODE_PACKX) {  // <= 4 channels, [row][col][4]
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int pc = lane; pc < a.PW; pc += 64) {
+                    const int ix = x0 + pc;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if ((unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < a.Cg)
+                                v[c] = a.g_nchw ? a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix]
+                                                : a.g[(((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c];
+                    }
+                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * 4]) = v;
+                }
+            }
         } else if (a.g_nchw) {
             for (int pr = wave; pr < a.PH; pr += 4) {
                 const int iy = y0 + pr;
                 for (int pc = lane; pc < a.PW; pc += 64) {
                     const int ix = x0 + pc;
                     const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
-                    float* dst = &patch[(pr * a.PW + pc) * G_CKP];
+                    float* dst = &patch[(pr * a.PW + pc) * ckp];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
                         float v = 0.f;
@@ -103,16 +142,29 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
                                 if (c + k < a.Cg) v[k] = src[k];
                         }
                     }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * G_CKP + 4 * q]) = v;
+                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * ckp + 4 * q]) = v;
                 }
             }
         }
-        // ---- stage the grid tensor tile: 128 pixels x BN channels, zero outside ------------------------------
-        if (a.dbg & 2) {
+        // ---- stage the grid tensor tile, zero outside -------------------------------------------------------------
+        if (mode == MODE_DPACK) {  // <= 4 channels, [8][htw][4], columns gx0 .. gx0 + htw
+            for (int e = tid; e < WT_H * a.htw; e += 256) {
+                const int r = e / a.htw, c = e % a.htw;
+                const int gy = ty0 * WT_H + r, gx = gx0 + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy < a.hH && (unsigned)gx < (unsigned)a.hW) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < a.Ch)
+                            v[k] = a.h_nchw ? a.h[(((size_t)n * a.h_ctot + a.h_coff + k) * a.hH + gy) * a.hW + gx]
+                                            : a.h[(((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + k];
+                }
+                *reinterpret_cast<f32x4*>(&ht[e * 4]) = v;
+            }
         } else if (a.h_nchw) {
             for (int c = wave; c < BN; c += 4) {
                 for (int p = lane; p < 128; p += 64) {
-                    const int gy = ty0 * WT_H + (p >> 4), gx = tx0 * WT_W + (p & 15);
+                    const int gy = ty0 * WT_H + (p >> 4), gx = gx0 + (p & 15);
                     float v = 0.f;
                     if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
                         v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
@@ -123,7 +175,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
             const bool al = ((a.h_ctot | a.h_coff) & 3) == 0;
             for (int e = tid; e < 128 * (BN / 4); e += 256) {
                 const int q = e % (BN / 4), p = e / (BN / 4);
-                const int gy = ty0 * WT_H + (p >> 4), gx = tx0 * WT_W + (p & 15);
+                const int gy = ty0 * WT_H + (p >> 4), gx = gx0 + (p & 15);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 const int c = h0 + 4 * q;
                 if (gy < a.hH && gx < a.hW && c < a.Ch) {
@@ -144,20 +196,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
 #pragma unroll 8
             for (int p = 0; p < 128; ++p) bsum += ht[p * BNP + tid];
         }
-        // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------
+        // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------------
+        const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
 #pragma unroll 1
-        for (int rr = 0; rr < ((a.dbg & 4) ? 0 : 2); ++rr) {
+        for (int rr = 0; rr < 2; ++rr) {
             const int r = 2 * wave + rr;
 #pragma unroll 1
             for (int xs = 0; xs < 4; ++xs) {
                 const int c = 4 * xs + g;  // this lane's k-slot pixel column
                 float bf[NFH];
 #pragma unroll
-                for (int hf = 0; hf < NFH; ++hf) bf[hf] = ht[(r * 16 + c) * BNP + 16 * hf + i];
+                for (int hf = 0; hf < NFH; ++hf) bf[hf] = ht[r * hrow + c * hcol + 16 * hf + i];
+                const int abase = (r * s * a.PW + c * s) * ckp + i;
 #pragma unroll
                 for (int t = 0; t < TG; ++t) {
                     if (t < tn) {
-                        const float af = patch[(r * s * a.PW + c * s) * G_CKP + toff[t] + i];
+                        const float af = patch[abase + toff[t]];
 #pragma unroll
                         for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = mfma16(af, bf[hf], acc[t][hf]);
                     }
@@ -192,13 +246,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
 #pragma unroll
         for (int t = 0; t < TG; ++t) {
             if (t >= tn) continue;
+            const int tt = t0 + t;
 #pragma unroll
             for (int hf = 0; hf < NFH; ++hf) {
-                const int hch = h0 + 16 * hf + i;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int gch = g0 + 4 * g + e;
-                    if (gch < a.Cg && hch < a.Ch) out[((size_t)(t0 + t) * a.Cg + gch) * a.Ch + hch] = acc[t][hf][e];
+                    // accumulator element: row m = 4g + e, column n = 16hf + i
+                    int tap, gch, hch;
+                    bool ok;
+                    if (mode == MODE_PLAIN) {
+                        tap = tt; gch = g0 + 4 * g + e; hch = h0 + 16 * hf + i;
+                        ok = gch < a.Cg && hch < a.Ch;
+                    } else if (mode == MODE_PACKX) {  // m = 4*kx_low + c
+                        const int kx = 4 * (tt % a.tapsx) + g;
+                        tap = (tt / a.tapsx) * a.KW + kx; gch = e; hch = h0 + 16 * hf + i;
+                        ok = kx < a.KW && gch < a.Cg && hch < a.Ch;
+                    } else {                          // n = 4*delta + co ; tap kx = 4j + 3 - delta
+                        const int kx = 4 * (tt % a.tapsx) + 3 - (i >> 2);
+                        tap = (tt / a.tapsx) * a.KW + kx; gch = g0 + 4 * g + e; hch = i & 3;
+                        ok = kx >= 0 && kx < a.KW && gch < a.Cg && hch < a.Ch;
+                    }
+                    if (ok) out[((size_t)tap * a.Cg + gch) * a.Ch + hch] = acc[t][hf][e];
                 }
             }
         }
@@ -235,33 +303,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 struct WGradPlan {
     int S, TGn, nz, nfh, tg;
-    size_t ws_bytes;
+    size_t ws_bytes, lds;
 };
 
 static WGradPlan plan_wgrad(const WGradArgs& a) {
     WGradPlan p;
-    p.nfh = a.Ch <= 16 ? 1 : 2;
-    if (a.T == 1) p.tg = 1;
-    else if (a.T <= 9) p.tg = 9;
+    if (a.Teff == 1) p.tg = 1;
+    else if (a.Teff <= 9) p.tg = 9;
     else p.tg = 16;
-    p.nz = cdiv(a.T, p.tg);
-    p.TGn = cdiv(a.T, p.nz);
-    const int ny = cdiv(a.Cg, 16) * cdiv(a.Ch, 16 * p.nfh);
+    // 16 taps x 2 column fragments = 128 accumulator + 152 other registers = one wave per SIMD; one fragment keeps three
+    p.nfh = (a.mode == MODE_DPACK || a.Ch <= 16 || p.tg == 16) ? 1 : 2;
+    p.nz = cdiv(a.Teff, p.tg);
+    p.TGn = cdiv(a.Teff, p.nz);
+    const int ny = a.n_gchunks * (a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16 * p.nfh));
     int S = 1024 / (ny * p.nz);
+    // keep the partial slabs small: they are written once and re-read once by the reduce kernel
+    const size_t slab = ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
+    while (S > 256 && (size_t)S * slab > ((size_t)48 << 20)) S >>= 1;
     if (S < 1) S = 1;
     if (S > a.ntiles) S = a.ntiles;
     p.S = S;
-    p.ws_bytes = (size_t)S * ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
+    p.ws_bytes = (size_t)S * slab;
+    const int bnp = 16 * p.nfh + 4;
+    const size_t htile = a.mode == MODE_DPACK ? (size_t)WT_H * a.htw * 4 : (size_t)128 * bnp;
+    p.lds = ((size_t)((a.PH * a.PW * a.ckp + 3) & ~3) + htile) * sizeof(float);
+    const size_t red = (size_t)p.tg * p.nfh * 256 * sizeof(float);
+    if (red > p.lds) p.lds = red;
     return p;
 }
 
 template <int TG, int NFH>
 static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
-    constexpr int BNP = 16 * NFH + 4;
-    size_t lds = ((size_t)((a.PH * a.PW * G_CKP + 3) & ~3) + 128 * BNP) * sizeof(float);
-    const size_t red = (size_t)TG * NFH * 256 * sizeof(float);
-    if (red > lds) lds = red;
-    if (lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: LDS patch too large");
+    if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: LDS patch too large");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<TG, NFH>),
@@ -269,8 +342,9 @@ static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
         if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad)");
         attr_set = true;
     }
-    dim3 grid(p.S, cdiv(a.Cg, 16) * cdiv(a.Ch, 16 * NFH), p.nz);
-    hipLaunchKernelGGL((wgrad_kernel<TG, NFH>), grid, dim3(256), lds, st, a);
+    const int ny = a.n_gchunks * (a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16 * NFH));
+    dim3 grid(p.S, ny, p.nz);
+    hipLaunchKernelGGL((wgrad_kernel<TG, NFH>), grid, dim3(256), p.lds, st, a);
     MSTG_CHECK_LAUNCH("wgrad_kernel");
     return MSTG_OK;
 }
@@ -287,12 +361,22 @@ static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float*
         a.h = dy; a.hH = d->Ho; a.hW = d->Wo; a.h_ctot = d->y_ctot; a.h_coff = d->y_coff; a.h_nchw = d->y_nchw; a.Ch = d->Cout;
         a.stride = d->stride; a.pad = d->pad;
     }
-    a.tiles_x = cdiv(a.hW, WT_W);
+    // operand packing: see the file header
+    a.mode = MODE_PLAIN;
+    if (a.Cg <= 4 && a.dil == 1 && a.KW > 1) a.mode = MODE_PACKX;
+    else if (a.Ch <= 4 && a.dil == 1 && a.stride == 1 && a.KW > 1) a.mode = MODE_DPACK;
+    { const char* e = getenv("MSTG_WGRAD_PLAIN"); if (e && e[0] == '1') a.mode = MODE_PLAIN; }
+    a.tapsx = cdiv(a.KW, 4);
+    a.xshift = a.mode == MODE_DPACK ? 3 : 0;
+    a.htw = a.mode == MODE_DPACK ? 20 : 16;
+    a.ckp = a.mode == MODE_PACKX ? 4 : 20;
+    a.Teff = a.mode == MODE_PLAIN ? a.T : a.KH * a.tapsx;
+    a.tiles_x = cdiv(a.hW + a.xshift, WT_W);
     a.tiles_y = cdiv(a.hH, WT_H);
     a.ntiles = a.N * a.tiles_x * a.tiles_y;
     a.PH = (WT_H - 1) * a.stride + (a.KH - 1) * a.dil + 1;
-    a.PW = (WT_W - 1) * a.stride + (a.KW - 1) * a.dil + 1;
-    a.n_gchunks = cdiv(a.Cg, 16);
+    a.PW = a.mode == MODE_PLAIN ? (WT_W - 1) * a.stride + (a.KW - 1) * a.dil + 1 : (WT_W - 1) * a.stride + 4 * a.tapsx;
+    a.n_gchunks = a.mode == MODE_PACKX ? 1 : cdiv(a.Cg, 16);
     if (a.g_nchw && a.Cg > 16) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: NCHW gathered tensor supports <= 16 channels");
     return MSTG_OK;
 }
@@ -318,12 +402,13 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient only for Conv2d (use mstg_channel_sum for ConvTranspose2d)");
     WGradArgs a{};
     if (int rc = fill_wgrad_args(d, x, dy, a)) return rc;
+    if (dbias && a.mode == MODE_DPACK)
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient not available for <= 4 output channels (use mstg_channel_sum / mstg_plane_sum)");
     const WGradPlan p = plan_wgrad(a);
     if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
     a.partial = (float*)workspace;
     a.TGn = p.TGn;
     a.with_bias = dbias != nullptr;
-    { const char* e = getenv("MSTG_DBG"); a.dbg = e ? atoi(e) : 0; }
     hipStream_t st = (hipStream_t)stream;
     int rc = MSTG_E_UNSUPPORTED;
     if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
@@ -335,7 +420,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     if (rc) return rc;
     const int T = a.T, total = T * a.Cg * a.Ch;
     // Conv2d: dw[co][ci][t] (gch = ci, hch = co) ; ConvTranspose2d: dw[ci][co][t] (gch = co, hch = ci)
-    const int s_g = d->transposed ? T : T;
+    const int s_g = T;
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
     const int pstride = total + (a.with_bias ? a.Ch : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, p.S, T, a.Cg, a.Ch, s_g, s_h,

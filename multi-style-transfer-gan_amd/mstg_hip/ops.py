@@ -194,7 +194,7 @@ class ConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             conv_dgrad_raw(d, dy, w, dx)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
+        fuse_db = want_db and ctx.needs_input_grad[1] and not transposed and Cout > 4  # <= 4: packed-column wgrad mode
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             if fuse_db:
@@ -243,8 +243,12 @@ class MSBranchesFn(torch.autograd.Function):
                 conv_dgrad_raw(d, dy, ws[j], dx)
             dw = torch.empty_like(ws[j])
             d.accumulate = 0
-            db = torch.empty(c4, dtype=torch.float32, device=dy.device)
-            conv_wgrad_raw(d, x, dy, dw, db)
+            if c4 > 4:
+                db = torch.empty(c4, dtype=torch.float32, device=dy.device)
+                conv_wgrad_raw(d, x, dy, dw, db)
+            else:  # <= 4 output channels: the wgrad kernel packs pixel shifts into its idle columns, bias summed apart
+                conv_wgrad_raw(d, x, dy, dw, None)
+                db = channel_sum(dy, N * H * W, 4 * c4, j * c4, c4)
             grads += [dw, db]
         return (dx, *grads)
 
@@ -353,6 +357,43 @@ class WindowAttnCoreFn(torch.autograd.Function):
         _timed(f"attn_core_bwd_kernel<{cp}>", 12 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_core_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, _stream()), "mstg_window_attn_core_bwd"))
         return dqkv
+
+
+class LocalAttentionFusedFn(torch.autograd.Function):
+    """Whole LocalAttention (qkv 1x1 conv -> window attention -> proj 1x1 conv) in one kernel per direction, C = 16 / 32.
+    x, y: NHWC (N,H,W,C); wqkv (3C,C,1,1), wproj (C,C,1,1) as stored by the reference."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, wproj, bproj):
+        x = _req(x, "attention input")
+        wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
+        N, H, W, Cn = x.shape
+        y = torch.empty_like(x)
+        _timed(f"attn_fused_fwd_kernel<{Cn}>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_fwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
+            "mstg_window_attn_fwd"))
+        ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, wqkv, bqkv, wproj, bproj = ctx.saved_tensors
+        dy = _req(dy, "attention grad_output")
+        N, H, W, Cn = x.shape
+        dx = torch.empty_like(x)
+        flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mstg_window_attn_bwd_workspace_bytes(N, H, W, Cn), x.device)
+        _timed(f"attn_fused_bwd_kernel<{Cn}>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+            lib.mstg_window_attn_bwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), _p(flat), N, H, W, Cn, _p(ws),
+                                     ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
+        c2 = Cn * Cn
+        return (dx, flat[:3 * c2].view(3 * Cn, Cn, 1, 1), flat[4 * c2:4 * c2 + 3 * Cn], flat[3 * c2:4 * c2].view(Cn, Cn, 1, 1),
+                flat[4 * c2 + 3 * Cn:])
+
+
+def fused_attention_supported(Cn: int) -> bool:
+    return bool(_lib.load().mstg_window_attn_fused_supported(int(Cn)))
 
 
 # ----------------------------------------------------------------------------------------------------------

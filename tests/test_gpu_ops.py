@@ -339,3 +339,27 @@ def test_flat_adam_matches_torch():
     for i, (pr, ph) in enumerate(zip(ps_ref, ps_hip)):
         report(f"flat adam param {i}", rel_l2(ph, pr), 1e-6)
     assert torch.equal(ps_hip[4].detach().cpu(), rnd(shapes[4], 74))
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 16), (1, 16, 16, 32), (3, 4, 4, 16), (1, 32, 64, 32), (1, 64, 64, 16)])
+def test_local_attention_fused_vs_oracle(N, H, W, C):
+    """The one-kernel LocalAttention (C = 16 / 32) against the oracle's local_attention on the CPU."""
+    from mstg_hip import ops
+    from oracle import restatement as R
+    spec = [("qkv.weight", (3 * C, C, 1, 1)), ("qkv.bias", (3 * C,)), ("proj.weight", (C, C, 1, 1)), ("proj.bias", (C,))]
+    sd = R.make_state_dict(spec, 900 + C)
+    x = rnd((N, C, H, W), 901 + C, 2.0)
+    sdr = {"p." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = R.local_attention(xr, sdr, "p", 4)
+    gy = rnd(tuple(yr.shape), 902)
+    gr = torch.autograd.grad((yr * gy).sum(), [xr] + list(sdr.values()))
+    xg = nhwc(x).to(DEV).requires_grad_(True)
+    pg = [sd[k].to(DEV).requires_grad_(True) for k in ("qkv.weight", "qkv.bias", "proj.weight", "proj.bias")]
+    assert ops.fused_attention_supported(C)
+    yg = ops.LocalAttentionFusedFn.apply(xg, *pg)
+    gg = torch.autograd.grad((yg * nhwc(gy).to(DEV)).sum(), [xg] + pg)
+    report(f"fused attention {N}x{H}x{W} C={C} y", rel_l2(nchw(yg), yr), 2e-5)
+    report(f"fused attention {N}x{H}x{W} C={C} dx", rel_l2(nchw(gg[0]), gr[0]), 1e-4)
+    for name, a, b in zip(("dWqkv", "dbqkv", "dWproj", "dbproj"), gg[1:], gr[1:]):
+        report(f"fused attention {N}x{H}x{W} C={C} {name}", rel_l2(a, b), 1e-4)
