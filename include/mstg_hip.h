@@ -58,6 +58,8 @@ typedef struct mstg_conv_desc {
     int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
 } mstg_conv_desc;
 
+/* name of the kernel a pass (0 forward, 1 dgrad, 2 wgrad) of this layer launches, as a profiler prints it (for reports) */
+const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass);
 /* workspace of fwd and dgrad: room for the filter re-packed into the order the kernel stages it (a few 100 KB at most) */
 size_t mstg_conv2d_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias /*nullable*/,

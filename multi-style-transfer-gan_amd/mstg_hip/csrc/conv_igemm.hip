@@ -605,7 +605,7 @@ int check_desc(const mstg_conv_desc* d) {
 
 using namespace mstg;
 
-static void fill_fwd_args(const mstg_conv_desc* d, IGemmArgs& a) {
+void fill_fwd_args(const mstg_conv_desc* d, IGemmArgs& a) {
     const int T = d->KH * d->KW;
     a.N = d->N;
     a.H = d->H; a.W = d->W; a.x_ctot = d->x_ctot; a.x_coff = d->x_coff; a.x_nchw = d->x_nchw; a.Cr = d->Cin;
@@ -621,7 +621,7 @@ static void fill_fwd_args(const mstg_conv_desc* d, IGemmArgs& a) {
     }
 }
 
-static int fill_dgrad_args(const mstg_conv_desc* d, IGemmArgs& a) {
+int fill_dgrad_args(const mstg_conv_desc* d, IGemmArgs& a) {
     const int T = d->KH * d->KW;
     a.N = d->N;
     // source = module output gradient, destination = module input gradient
@@ -673,6 +673,20 @@ extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const
     if (int rc = fill_dgrad_args(d, a)) return rc;
     a.x = dy; a.y = dx; a.w = w; a.bias = nullptr;
     return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// kernel symbol (as rocprofv3 prints it, without namespace/arguments) a forward (0) / dgrad (1) call would launch
+const char* igemm_kernel_name(const mstg_conv_desc* d, int pass) {
+    static thread_local char name[64];
+    IGemmArgs a{};
+    IGemmPlan p;
+    if (check_desc(d)) return "";
+    if (pass == 0) fill_fwd_args(d, a);
+    else if (fill_dgrad_args(d, a)) return "";
+    if (plan_igemm(a, p)) return "";
+    if (p.heavy) snprintf(name, sizeof(name), "igemm_heavy_kernel<%d, %d, %d>", p.V, p.nfw, p.src);
+    else snprintf(name, sizeof(name), "igemm_light_kernel<%d, %d>", p.V, p.nfw);
+    return name;
 }
 
 extern "C" const char* mstg_version(void) { return "mstg-hip 0.1.0 gfx950"; }

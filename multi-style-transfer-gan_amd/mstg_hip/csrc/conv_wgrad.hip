@@ -273,6 +273,200 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
     }
 }
 
+// =====================================================================================================================
+// Tap-split variant (every filter with more than one tap).  The accumulator "units" (tap x 16-wide grid-channel fragment)
+// of a (gathered-chunk, grid-channel-group) pair are dealt round-robin to the four waves and every wave walks ALL pixels
+// of the tile.  Compared with splitting the pixels: one workgroup covers up to 64 grid channels with one staging of the
+// patch (4x less re-staging), a wave keeps only UW accumulators (occupancy), and no cross-wave reduction is needed.
+// TH (4 or 8) is the tile height: stride-2 patches are large, a 4-row tile keeps three workgroups per CU.
+// =====================================================================================================================
+template <int UW>
+__global__ __launch_bounds__(256) void wgrad_ts_kernel(const WGradArgs a, const int TH, const int NFHT) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ckp = a.ckp, s = a.stride, mode = a.mode;
+    const int BNP = 16 * NFHT + 4;
+    float* patch = smem;                                        // [PH][PW][ckp]
+    float* ht = smem + ((a.PH * a.PW * ckp + 3) & ~3);          // plain/packx: [TH*16][BNP]; dpack: [TH][htw][4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int gchunk = blockIdx.y % a.n_gchunks, hgroup = blockIdx.y / a.n_gchunks;
+    const int g0 = gchunk * 16, h0 = hgroup * 16 * NFHT;
+    const int U = a.Teff * NFHT;  // units of this workgroup; unit u -> tap u / NFHT, fragment u % NFHT
+
+    f32x4 acc[UW];
+    int toff[UW], hfo[UW];
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        const int u = min(wave + 4 * k, U - 1);
+        const int tt = u / NFHT, hf = u % NFHT;
+        int ky, kxo;
+        if (mode == MODE_PLAIN) { ky = tt / a.KW; kxo = (tt % a.KW) * a.dil; }
+        else if (mode == MODE_PACKX) { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx); }
+        else { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx) + 3; }
+        toff[k] = (ky * a.dil * a.PW + kxo) * ckp;
+        hfo[k] = 16 * hf;
+        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nu = (U - wave + 3) / 4;  // units this wave really owns
+
+    const bool do_bias = a.with_bias && gchunk == 0;
+    float bsum = 0.f;  // thread c < 16*NFHT: running column sum of grid channel h0 + c
+    const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
+        const int gx0 = tx0 * WT_W - a.xshift;
+        const int y0 = ty0 * TH * s - a.pad, x0 = gx0 * s - a.pad;
+        __syncthreads();
+        // ---- stage the gathered patch ------------------------------------------------------------------------------
+        if (mode == MODE_PACKX) {
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int pc = lane; pc < a.PW; pc += 64) {
+                    const int ix = x0 + pc;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if ((unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < a.Cg)
+                                v[c] = a.g_nchw ? a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix]
+                                                : a.g[(((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c];
+                    }
+                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * 4]) = v;
+                }
+            }
+        } else if (a.g_nchw) {
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int pc = lane; pc < a.PW; pc += 64) {
+                    const int ix = x0 + pc;
+                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                    float* dst = &patch[(pr * a.PW + pc) * ckp];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        float v = 0.f;
+                        if (inb && c < a.Cg) v = a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix];
+                        dst[c] = v;
+                    }
+                }
+            }
+        } else {
+            const bool al = ((a.g_ctot | a.g_coff) & 3) == 0;
+            for (int pr = wave; pr < a.PH; pr += 4) {
+                const int iy = y0 + pr;
+                for (int e = lane; e < a.PW * 4; e += 64) {
+                    const int pc = e >> 2, q = e & 3;
+                    const int ix = x0 + pc;
+                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int c = g0 + 4 * q;
+                    if (inb && c < a.Cg) {
+                        const float* src = a.g + (((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c;
+                        if (al && c + 3 < a.Cg) {
+                            v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (c + k < a.Cg) v[k] = src[k];
+                        }
+                    }
+                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * ckp + 4 * q]) = v;
+                }
+            }
+        }
+        // ---- stage the grid tensor tile --------------------------------------------------------------------------------
+        if (mode == MODE_DPACK) {
+            for (int e = tid; e < TH * a.htw; e += 256) {
+                const int r = e / a.htw, c = e % a.htw;
+                const int gy = ty0 * TH + r, gx = gx0 + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (gy < a.hH && (unsigned)gx < (unsigned)a.hW) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k < a.Ch)
+                            v[k] = a.h_nchw ? a.h[(((size_t)n * a.h_ctot + a.h_coff + k) * a.hH + gy) * a.hW + gx]
+                                            : a.h[(((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + k];
+                }
+                *reinterpret_cast<f32x4*>(&ht[e * 4]) = v;
+            }
+        } else if (a.h_nchw) {
+            for (int c = wave; c < 16 * NFHT; c += 4) {
+                for (int p = lane; p < TH * 16; p += 64) {
+                    const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
+                    float v = 0.f;
+                    if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
+                        v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
+                    ht[p * BNP + c] = v;
+                }
+            }
+        } else {
+            const bool al = ((a.h_ctot | a.h_coff) & 3) == 0;
+            const int nq = 4 * NFHT;
+            for (int e = tid; e < TH * 16 * nq; e += 256) {
+                const int q = e % nq, p = e / nq;
+                const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int c = h0 + 4 * q;
+                if (gy < a.hH && gx < a.hW && c < a.Ch) {
+                    const float* src = a.h + (((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + c;
+                    if (al && c + 3 < a.Ch) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (c + k < a.Ch) v[k] = src[k];
+                    }
+                }
+                *reinterpret_cast<f32x4*>(&ht[p * BNP + 4 * q]) = v;
+            }
+        }
+        __syncthreads();
+        if (do_bias && tid < 16 * NFHT) {
+            for (int p = 0; p < TH * 16; ++p) bsum += ht[p * BNP + tid];
+        }
+        // ---- MFMA: every wave walks all TH x 16 pixels (4 per k-step) for its own units -----------------------------------
+#pragma unroll 1
+        for (int r = 0; r < TH; ++r) {
+#pragma unroll 1
+            for (int xs = 0; xs < 4; ++xs) {
+                const int c = 4 * xs + g;
+                const int abase = (r * s * a.PW + c * s) * ckp + i;
+                const int hbase = r * hrow + c * hcol + i;
+#pragma unroll
+                for (int k = 0; k < UW; ++k) {
+                    if (k < nu) acc[k] = mfma16(patch[abase + toff[k]], ht[hbase + hfo[k]], acc[k]);
+                }
+            }
+        }
+    }
+    // ---- each wave writes the partial of its own units; no cross-wave reduction ------------------------------------------
+    const size_t pstride = (size_t)a.T * a.Cg * a.Ch + (a.with_bias ? a.Ch : 0);
+    if (do_bias && tid < 16 * NFHT && h0 + tid < a.Ch) a.partial[(size_t)blockIdx.x * pstride + (size_t)a.T * a.Cg * a.Ch + h0 + tid] = bsum;
+    float* out = a.partial + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        if (k >= nu) continue;
+        const int u = wave + 4 * k, tt = u / NFHT, hf = u % NFHT;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int tap, gch, hch;
+            bool ok;
+            if (mode == MODE_PLAIN) {
+                tap = tt; gch = g0 + 4 * g + e; hch = h0 + 16 * hf + i;
+                ok = gch < a.Cg && hch < a.Ch;
+            } else if (mode == MODE_PACKX) {
+                const int kx = 4 * (tt % a.tapsx) + g;
+                tap = (tt / a.tapsx) * a.KW + kx; gch = e; hch = h0 + 16 * hf + i;
+                ok = kx < a.KW && gch < a.Cg && hch < a.Ch;
+            } else {
+                const int kx = 4 * (tt % a.tapsx) + 3 - (i >> 2);
+                tap = (tt / a.tapsx) * a.KW + kx; gch = g0 + 4 * g + e; hch = i & 3;
+                ok = kx >= 0 && kx < a.KW && gch < a.Cg && hch < a.Ch;
+            }
+            if (ok) out[((size_t)tap * a.Cg + gch) * a.Ch + hch] = acc[k][e];
+        }
+    }
+}
+
 // dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]  (+ dbias[hch] from the tail of each split's block).
 // A workgroup owns 16 consecutive outputs; its 16 thread-rows stride over the splits and are combined through LDS in a
 // fixed order, so the result does not depend on scheduling.
@@ -349,6 +543,53 @@ static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
     return MSTG_OK;
 }
 
+struct TsPlan {
+    int TH, NFHT, UW, S, ngroups;
+    size_t lds, ws_bytes;
+};
+
+static TsPlan plan_ts(WGradArgs& a) {
+    TsPlan p;
+    p.TH = a.stride >= 2 ? 4 : 8;
+    // re-derive the tile geometry for this tile height
+    a.tiles_y = cdiv(a.hH, p.TH);
+    a.ntiles = a.N * a.tiles_x * a.tiles_y;
+    a.PH = (p.TH - 1) * a.stride + (a.KH - 1) * a.dil + 1;
+    const int nfh_all = a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16);
+    p.NFHT = nfh_all > 4 ? 4 : nfh_all;
+    while (a.Teff * p.NFHT > 64) --p.NFHT;  // at most 16 units per wave
+    p.ngroups = cdiv(nfh_all, p.NFHT);
+    const int U = a.Teff * p.NFHT;
+    p.UW = U <= 16 ? 4 : (U <= 32 ? 8 : 16);
+    const int ny = a.n_gchunks * p.ngroups;
+    int S = 768 / ny;
+    const size_t slab = ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
+    while (S > 128 && (size_t)S * slab > ((size_t)48 << 20)) S >>= 1;
+    if (S < 1) S = 1;
+    if (S > a.ntiles) S = a.ntiles;
+    p.S = S;
+    p.ws_bytes = (size_t)S * slab;
+    const size_t htile = a.mode == MODE_DPACK ? (size_t)p.TH * a.htw * 4 : (size_t)p.TH * 16 * (16 * p.NFHT + 4);
+    p.lds = ((size_t)((a.PH * a.PW * a.ckp + 3) & ~3) + htile) * sizeof(float);
+    return p;
+}
+
+template <int UW>
+static int launch_ts_t(WGradArgs& a, const TsPlan& p, hipStream_t st) {
+    if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: LDS patch too large");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ts_kernel<UW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad_ts)");
+        attr_set = true;
+    }
+    dim3 grid(p.S, a.n_gchunks * p.ngroups, 1);
+    hipLaunchKernelGGL((wgrad_ts_kernel<UW>), grid, dim3(256), p.lds, st, a, p.TH, p.NFHT);
+    MSTG_CHECK_LAUNCH("wgrad_ts_kernel");
+    return MSTG_OK;
+}
+
 static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float* dy, WGradArgs& a) {
     a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.dil = d->dil; a.T = d->KH * d->KW;
@@ -387,11 +628,30 @@ int check_desc(const mstg_conv_desc* d);  // conv_igemm.hip
 
 using namespace mstg;
 
+const char* igemm_kernel_name(const mstg_conv_desc* d, int pass);  // conv_igemm.hip
+
+extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass) {
+    if (pass != 2) return igemm_kernel_name(d, pass);
+    static thread_local char name[64];
+    WGradArgs a{};
+    if (check_desc(d) || fill_wgrad_args(d, nullptr, nullptr, a)) return "";
+    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
+    if (use_ts) {
+        snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", plan_ts(a).UW);
+    } else {
+        const WGradPlan p = plan_wgrad(a);
+        snprintf(name, sizeof(name), "wgrad_kernel<%d, %d>", p.tg, p.nfh);
+    }
+    return name;
+}
+
 extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     if (check_desc(d)) return 0;
     WGradArgs a{};
     if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
-    return plan_wgrad(a).ws_bytes;
+    const size_t w_old = plan_wgrad(a).ws_bytes;
+    const size_t w_ts = a.Teff > 1 ? plan_ts(a).ws_bytes : 0;
+    return w_old > w_ts ? w_old : w_ts;
 }
 
 extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -404,26 +664,39 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     if (int rc = fill_wgrad_args(d, x, dy, a)) return rc;
     if (dbias && a.mode == MODE_DPACK)
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient not available for <= 4 output channels (use mstg_channel_sum / mstg_plane_sum)");
-    const WGradPlan p = plan_wgrad(a);
-    if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
-    a.partial = (float*)workspace;
-    a.TGn = p.TGn;
-    a.with_bias = dbias != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int rc = MSTG_E_UNSUPPORTED;
-    if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
-    else if (p.tg == 1 && p.nfh == 2) rc = launch_wgrad_t<1, 2>(a, p, st);
-    else if (p.tg == 9 && p.nfh == 1) rc = launch_wgrad_t<9, 1>(a, p, st);
-    else if (p.tg == 9 && p.nfh == 2) rc = launch_wgrad_t<9, 2>(a, p, st);
-    else if (p.tg == 16 && p.nfh == 1) rc = launch_wgrad_t<16, 1>(a, p, st);
-    else if (p.tg == 16 && p.nfh == 2) rc = launch_wgrad_t<16, 2>(a, p, st);
-    if (rc) return rc;
+    a.partial = (float*)workspace;
+    a.with_bias = dbias != nullptr;
+    int S;
+    // measured on MI355X: the tap-split kernel wins where a workgroup gets 32 units (16 taps x 2 column fragments: the
+    // stride-2 / transposed 4x4 layers with 17..32 grid channels); the pixel-split kernel elsewhere
+    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
+    if (use_ts && !(getenv("MSTG_WGRAD_OLD") && getenv("MSTG_WGRAD_OLD")[0] == '1')) {
+        const TsPlan p = plan_ts(a);
+        if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+        int rc = p.UW == 4 ? launch_ts_t<4>(a, p, st) : (p.UW == 8 ? launch_ts_t<8>(a, p, st) : launch_ts_t<16>(a, p, st));
+        if (rc) return rc;
+        S = p.S;
+    } else {
+        const WGradPlan p = plan_wgrad(a);
+        if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+        a.TGn = p.TGn;
+        int rc = MSTG_E_UNSUPPORTED;
+        if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
+        else if (p.tg == 1 && p.nfh == 2) rc = launch_wgrad_t<1, 2>(a, p, st);
+        else if (p.tg == 9 && p.nfh == 1) rc = launch_wgrad_t<9, 1>(a, p, st);
+        else if (p.tg == 9 && p.nfh == 2) rc = launch_wgrad_t<9, 2>(a, p, st);
+        else if (p.tg == 16 && p.nfh == 1) rc = launch_wgrad_t<16, 1>(a, p, st);
+        else if (p.tg == 16 && p.nfh == 2) rc = launch_wgrad_t<16, 2>(a, p, st);
+        if (rc) return rc;
+        S = p.S;
+    }
     const int T = a.T, total = T * a.Cg * a.Ch;
     // Conv2d: dw[co][ci][t] (gch = ci, hch = co) ; ConvTranspose2d: dw[ci][co][t] (gch = co, hch = ci)
     const int s_g = T;
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
     const int pstride = total + (a.with_bias ? a.Ch : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, p.S, T, a.Cg, a.Ch, s_g, s_h,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
                        pstride);
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;

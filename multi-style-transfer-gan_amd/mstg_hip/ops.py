@@ -95,16 +95,15 @@ def _conv_cost(d: ConvDesc):
     return 2 * macs, nbytes
 
 
-def _igemm_symbol(cr, co, src_nchw):
-    v = 1 if src_nchw else (4 if cr % 16 == 0 else (2 if cr % 8 == 0 else 1))
-    return f"igemm_kernel<{v},{1 if co <= 16 else (2 if co <= 32 else 4)}>"
+def _kernel_name(d: ConvDesc, which: int) -> str:
+    return _lib.load().mstg_conv2d_kernel_name(C.byref(d), which).decode() if KernelTimer.enabled else ""
 
 
 def conv_fwd_raw(d: ConvDesc, x, w, b, y):
     fl, by = _conv_cost(d)
     lib = _lib.load()
     ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
-    _timed(_igemm_symbol(d.Cin, d.Cout, d.x_nchw), fl, by, lambda: _lib.check(
+    _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
         lib.mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_fwd"),
         _conv_detail("fwd", d))
 
@@ -113,7 +112,7 @@ def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
     fl, by = _conv_cost(d)
     lib = _lib.load()
     ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
-    _timed(_igemm_symbol(d.Cout, d.Cin, d.y_nchw), fl, by, lambda: _lib.check(
+    _timed(_kernel_name(d, 1), fl, by, lambda: _lib.check(
         lib.mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_dgrad"),
         _conv_detail("dgrad", d))
 
@@ -124,9 +123,7 @@ def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):
     nbytes = lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d))
     ws = _ws(nbytes, x.device)
     fl, by = _conv_cost(d)
-    T = d.KH * d.KW
-    ch = d.Cin if d.transposed else d.Cout
-    sym = f"wgrad_kernel<{1 if T == 1 else (9 if T <= 9 else 16)},{1 if ch <= 16 else 2}>"
+    sym = _kernel_name(d, 2)
     _timed(sym, fl, by, lambda: _lib.check(
         lib.mstg_conv2d_wgrad(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_wgrad"),
         _conv_detail("wgrad", d))
