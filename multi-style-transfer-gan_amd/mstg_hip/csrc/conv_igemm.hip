@@ -35,7 +35,8 @@ struct IGemmArgs {
     int TG;                             // taps per weight-staging group
     int ntaps;
     int act, accumulate;
-    int dbg;  // ablation bits for tools/bench_conv.py (MSTG_DBG): 1 skip filter staging, 2 skip patch staging, 4 skip MFMA
+    int dbg;
+    int dpack, tapsx;  // <= 4 output channels: rows of the MFMA tile = (pixel shift delta, channel), see igemm_light_kernel
 };
 
 constexpr int TILE_H = 8, TILE_W = 16;
@@ -63,15 +64,21 @@ __global__ void pack_filter_kernel(const IGemmArgs a, float* __restrict__ wp, in
         const int co = rest % CoP; rest /= CoP;
         const int t = rest % a.ntaps; rest /= a.ntaps;
         const int chunk = rest % nchunks, cls = rest / nchunks;
-        int widx;
+        int widx, oc = co;
+        bool ok = true;
         if (a.phase) {
             const int pa = cls >> 1, pb = cls & 1, u = t >> 1, v = t & 1;
             widx = ((1 - pa) + 2 * u) * 4 + ((1 - pb) + 2 * v);
+        } else if (a.dpack) {  // row = 4*delta + channel ; packed tap t = (ky, j) holds the real tap kx = 4j + 3 - delta
+            const int delta = co >> 2, kx = 4 * (t % a.tapsx) + 3 - delta, real = (t / a.tapsx) * a.KW + kx;
+            oc = co & 3;
+            ok = co < 16 && kx >= 0 && kx < a.KW;
+            widx = a.flip ? (a.KH * a.KW - 1 - real) : real;
         } else {
             widx = a.flip ? (a.ntaps - 1 - t) : t;
         }
         const int cr = chunk * CK + ci;
-        wp[idx] = (co < a.Co && cr < a.Cr) ? a.w[(size_t)co * a.w_so + (size_t)cr * a.w_sr + widx] : 0.f;
+        wp[idx] = (ok && oc < a.Co && cr < a.Cr) ? a.w[(size_t)oc * a.w_so + (size_t)cr * a.w_sr + widx] : 0.f;
     }
 }
 
@@ -81,6 +88,9 @@ __device__ __forceinline__ int tap_patch_offset(const IGemmArgs& a, int t, int p
     if (a.phase) {
         pro = 1 + pa - (t >> 1);
         pco = 1 + pb - (t & 1);
+    } else if (a.dpack) {
+        pro = t / a.tapsx;
+        pco = 4 * (t % a.tapsx) + 3;
     } else {
         pro = (t / a.KW) * a.dil;
         pco = (t % a.KW) * a.dil;
@@ -148,7 +158,8 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
     const int cls = blockIdx.z, pa = cls >> 1, pb = cls & 1;
     const int s = a.phase ? 1 : a.stride;
     const int y0 = a.phase ? ty0 * TILE_H - 1 : ty0 * TILE_H * s - a.pad;
-    const int x0 = a.phase ? tx0 * TILE_W - 1 : tx0 * TILE_W * s - a.pad;
+    // dpack: tiles advance by 13 output columns; the 16 accumulator columns start 3 pixels to their left
+    const int x0 = a.phase ? tx0 * TILE_W - 1 : (a.dpack ? tx0 * 13 - 3 - a.pad : tx0 * TILE_W * s - a.pad);
     const int nchunks = (a.Cr + CK - 1) / CK;
 
     f32x4 acc[NFW][2];
@@ -234,7 +245,35 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
             }
         }
     }
-    igemm_epilogue<NFW>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+    if (!a.dpack) {
+        igemm_epilogue<NFW>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+        return;
+    }
+    // ---- dpack epilogue.  Accumulator row 4*delta + c of pixel column p is a partial sum of output column p + delta:
+    //      y[q][c] = sum_delta D[delta][q - delta].  Exchange through LDS, then lanes (q < 13, pf) finish 13 columns. ---------
+    __syncthreads();  // everybody is done with the filter / patch tiles: reuse the front of LDS
+    float* comb = smem + wave * 512;  // [pf][delta][p][4]
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) *reinterpret_cast<f32x4*>(&comb[((pf * 4 + g) * 16 + i) * 4]) = acc[0][pf];
+    __syncthreads();
+    if (g < 2 && i < 13) {
+        const int pf = g;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) v += *reinterpret_cast<const f32x4*>(&comb[((pf * 4 + d) * 16 + i + 3 - d) * 4]);
+        const int oy = ty0 * TILE_H + 2 * wave + pf, ox = tx0 * 13 + i;
+        if (oy < a.Gh && ox < a.Gw) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= a.Co) continue;
+                float* p = a.y_nchw ? a.y + (((size_t)n * a.y_ctot + a.y_coff + e) * a.Ho + oy) * a.Wo + ox
+                                    : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + e;
+                float val = v[e] + (a.bias ? a.bias[e] : 0.f);
+                if (a.accumulate) val += *p;
+                *p = apply_act(val, a.act);
+            }
+        }
+    }
 }
 
 // =====================================================================================================================
@@ -456,10 +495,20 @@ struct IGemmPlan {
 static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     a.tiles_x = cdiv(a.Gw, TILE_W);
     a.tiles_y = cdiv(a.Gh, TILE_H);
+    // <= 4 output channels (the RGB head, the stem's input gradient, the discriminator heads, 4-channel branches): pack four
+    // horizontally adjacent taps into the 16 filter rows of the MFMA tile instead of padding 4 channels to 16
+    a.dpack = !a.phase && a.Co <= 4 && a.stride == 1 && a.dil == 1 && a.KW > 1;
+    { const char* e = getenv("MSTG_NO_DPACK"); if (e && e[0] == '1') a.dpack = 0; }
+    a.tapsx = cdiv(a.KW, 4);
     if (a.phase) {
         a.PH = TILE_H + 2;
         a.PW = TILE_W + 2;
         a.ntaps = 4;
+    } else if (a.dpack) {
+        a.tiles_x = cdiv(a.Gw, 13);
+        a.PH = (TILE_H - 1) + (a.KH - 1) + 1;
+        a.PW = (TILE_W - 1) + 4 * a.tapsx;
+        a.ntaps = a.KH * a.tapsx;
     } else {
         a.PH = (TILE_H - 1) * a.stride + (a.KH - 1) * a.dil + 1;
         a.PW = (TILE_W - 1) * a.stride + (a.KW - 1) * a.dil + 1;
@@ -491,7 +540,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     const size_t lds_heavy = 2 * (patch_floats + (size_t)tgh * p.BN * p.CKP) * sizeof(float);
     // heavy = enough MFMAs per stage and wave to cover the latency of the next stage's loads
     const int mfma_per_stage = tgh * p.nfw * 2 * p.V;
-    p.heavy = tgh >= 1 && mfma_per_stage >= 64 && a.PH <= 255 && a.PW <= 255 && a.PH * a.PW * p.V <= NPQ * 256 &&
+    p.heavy = !a.dpack && tgh >= 1 && mfma_per_stage >= 64 && a.PH <= 255 && a.PW <= 255 && a.PH * a.PW * p.V <= NPQ * 256 &&
               lds_heavy <= 160 * 1024 && !(p.src == 2 && p.V != 1) && !(p.src == 0 && a.Cr < 4);
     // measured on MI355X: with the packed filter the high-occupancy kernel wins everywhere except on deep-channel layers
     // with few tiles (the discriminator's 32x32 / 16x16 maps), where a workgroup has too few neighbours to hide behind
@@ -503,6 +552,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     } else {
         p.TG = a.TG = tg;
         p.lds = (patch_floats + (size_t)tg * p.BN * p.CKP) * sizeof(float);
+        if (a.dpack && p.lds < 4 * 512 * sizeof(float)) p.lds = 4 * 512 * sizeof(float);  // room for the shift-combine exchange
         if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv: LDS patch too large for this geometry");
     }
     return MSTG_OK;
