@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--channels", type=int, default=16)
+    ap.add_argument("--style-loss", action="store_true",
+                    help="add the build-defined VGG/Gram multi-style loss (3 weighted references) to the step; NOT the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table of the instrumented step to stderr")
@@ -87,6 +89,10 @@ def main():
     torch.manual_seed(42)  # reference seeds with set_seed(42) (pretrain.py:13-17); every rank builds the same weights
     model = enhanced_train.EnhancedCycleGAN(channels=args.channels, num_transformer_blocks=0, device=dev)
     model.sync_replicas()
+    if args.style_loss:
+        sgen = [torch.Generator().manual_seed(2001 + k) for k in range(3)]
+        refs = [(torch.rand((4, 3, args.size, args.size), generator=g_) * 2 - 1) for g_ in sgen]
+        model.attach_style_loss(refs, (0.5, 0.3, 0.2), lambda_style=1.0)
     gen = torch.Generator().manual_seed(1234 + dp.rank())
     shape = (args.batch, 3, args.size, args.size)
     real_A = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
@@ -149,7 +155,8 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"reference CycleGAN train_step (2x EnhancedGenerator + 2x EnhancedDiscriminator, channels={args.channels}, "
-                                       f"num_transformer_blocks=0), {args.batch} image pairs/GPU at {args.size}x{args.size}, fwd+bwd+loss+Adam",
+                                       f"num_transformer_blocks=0), {args.batch} image pairs/GPU at {args.size}x{args.size}, fwd+bwd+loss+Adam"
+                                       + (" + build-defined VGG16/Gram multi-style loss (3 refs)" if args.style_loss else ""),
                            "pairs_per_gpu": args.batch, "images_per_step_per_gpu": 2 * args.batch, "size": args.size,
                            "channels": args.channels, "parallelism": f"dp{world}", "losses_finite": finite},
                 "roofline": roofline, "cpu_baseline": cpu}

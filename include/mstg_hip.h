@@ -54,7 +54,7 @@ typedef struct mstg_conv_desc {
     int32_t x_nchw, y_nchw; /* 1: that tensor is NCHW (3-channel image boundary), else NHWC */
     int32_t x_ctot, x_coff; /* module input  = channels [x_coff, x_coff+Cin)  of an NHWC tensor with x_ctot channels */
     int32_t y_ctot, y_coff; /* module output = channels [y_coff, y_coff+Cout) of an NHWC tensor with y_ctot channels */
-    int32_t act;            /* forward epilogue activation applied after bias: MSTG_ACT_NONE or MSTG_ACT_TANH */
+    int32_t act;            /* forward epilogue activation applied after bias: MSTG_ACT_NONE / _RELU / _LEAKY02 / _TANH */
     int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
 } mstg_conv_desc;
 
@@ -143,6 +143,21 @@ int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, float* dx, vo
 /* torch.optim.Adam step over one flat fp32 buffer (enhanced_train.py:36-43: betas (0.5,0.999), eps 1e-8) */
 int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                         float eps, int step, const unsigned char* mask /*nullable: 0 = skip element*/, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Build-defined multi-style perceptual loss pieces.  The reference has NO implementation of them (the
+ * north star's "VGG-feature Gram-matrix / perceptual style loss" is a README bullet only) -- parity unpinned.
+ * The VGG-topology 3x3 convolutions go through mstg_conv2d_* (ReLU = epilogue activation MSTG_ACT_RELU).
+ *   max-pool 2x2/2 on NHWC with the arg-max slot (0..3, row-major window order, first maximum wins like torch) per element;
+ *   Gram: g[n] = scale * F[n]^T F[n], F[n] = NHWC features viewed (HW, C), C a multiple of 16;
+ *   Gram backward: df[n] = scale * F[n] (dg[n] + dg[n]^T).
+ * ---------------------------------------------------------------------------------------------- */
+int mstg_maxpool2x2_fwd(const float* x, float* y, unsigned char* idx, int N, int H, int W, int C, void* stream);
+int mstg_maxpool2x2_bwd(const float* dy, const unsigned char* idx, float* dx, int N, int H, int W, int C, void* stream);
+size_t mstg_gram_workspace_bytes(int N, int HW, int C);
+int mstg_gram_fwd(const float* f, float* g, int N, int HW, int C, float scale, void* workspace, size_t workspace_bytes,
+                  void* stream);
+int mstg_gram_bwd(const float* f, const float* dg, float* df, int N, int HW, int C, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,7 @@ from mstg_hip import dp, ops
 from mstg_hip.optim import FlatAdam
 
 LOSS_KEYS = ("d_loss", "g_loss", "cycle_loss", "identity_loss", "structure_loss")
+STYLE_KEY = "style_loss"  # only present when a multi-style loss is attached (build-defined extension, see style_loss.py)
 
 
 class _NoScaler:
@@ -80,6 +81,17 @@ class EnhancedCycleGAN:
         self.lambda_identity = 2.0
         self.lambda_structure = 0.5
         self.batch_generator_passes = True  # see train_step_async
+        self.style_loss = None              # optional build-defined multi-style Gram loss on G_BA's output
+        self.lambda_style = 0.0
+
+    def attach_style_loss(self, style_refs, style_weights=(0.5, 0.3, 0.2), lambda_style=1.0, width_div=1, seed=1234):
+        """BUILD-DEFINED extension (the reference has no style loss): add
+        ``lambda_style * MultiStyleGramLoss(fake_A)`` to the generator objective, fake_A = G_BA(real_B) being the stylised
+        image.  ``style_refs``: sequence of (N,3,H,W) tensors in [-1,1]; targets are computed once, here."""
+        import style_loss as sl
+        feats = sl.VGGFeatures(width_div=width_div, seed=seed).to(self.device)
+        self.style_loss = sl.MultiStyleGramLoss(feats, [r.to(self.device) for r in style_refs], style_weights)
+        self.lambda_style = float(lambda_style)
 
     def _build_optimizers(self):
         self.g_optimizer = FlatAdam(itertools.chain(self.G_AB.parameters(), self.G_BA.parameters()), lr=5e-5, betas=(0.5, 0.999))
@@ -146,17 +158,24 @@ class EnhancedCycleGAN:
             _, fake_B_struct = D_B(fake_B)
             structure_loss = (ops.l1_loss(real_A_struct, fake_A_struct) + ops.l1_loss(real_B_struct, fake_B_struct)) * self.lambda_structure
             total_g_loss = g_loss + cycle_loss + identity_loss + structure_loss
+            style = None
+            if self.style_loss is not None:
+                style = self.style_loss(fake_A) * self.lambda_style
+                total_g_loss = total_g_loss + style
             total_g_loss.backward()
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
         dp.allreduce_mean_(self.g_optimizer.grad)
         self.g_optimizer.step()
-        return torch.stack([d_loss.detach(), g_loss.detach(), cycle_loss.detach(), identity_loss.detach(), structure_loss.detach()])
+        out = [d_loss.detach(), g_loss.detach(), cycle_loss.detach(), identity_loss.detach(), structure_loss.detach()]
+        if style is not None:
+            out.append(style.detach())
+        return torch.stack(out)
 
     def train_step(self, real_A, real_B):
         vals = self.train_step_async(real_A, real_B).tolist()  # one device sync
-        return dict(zip(LOSS_KEYS, vals))
+        return dict(zip(LOSS_KEYS + ((STYLE_KEY,) if self.style_loss is not None else ()), vals))
 
     def save_models(self, save_dir, epoch):  # reference :133-152
         save_path = Path(save_dir)

@@ -52,6 +52,11 @@ SIGNATURES = {
     "mstg_plane_sum": (_i, [_fp, _i, _i, _sz, _f, _fp, _vp, _sz, _vp]),
     "mstg_segment_mean_fwd": (_i, [_fp, _i, _sz, _i, _fp, _vp]),
     "mstg_segment_mean_bwd": (_i, [_fp, _i, _sz, _i, _fp, _vp]),
+    "mstg_maxpool2x2_fwd": (_i, [_fp, _fp, _vp, _i, _i, _i, _i, _vp]),
+    "mstg_maxpool2x2_bwd": (_i, [_fp, _vp, _fp, _i, _i, _i, _i, _vp]),
+    "mstg_gram_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mstg_gram_fwd": (_i, [_fp, _fp, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "mstg_gram_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _vp]),
     "mstg_adam_step_flat": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _i, _vp, _vp]),
 }
 

@@ -174,7 +174,7 @@ class ConvFn(torch.autograd.Function):
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
         conv_fwd_raw(d, x, w, b, y)
         ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
-        ctx.save_for_backward(x, w, y if act == ACT_TANH else None)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -183,8 +183,8 @@ class ConvFn(torch.autograd.Function):
         N, H, W, Cin, Ho, Wo, Cout = ctx.dims
         x, w, y = ctx.saved_tensors
         dy = _req(dy, "conv grad_output")
-        if act == ACT_TANH:
-            dy = act_bwd_raw(y, dy, ACT_TANH)
+        if act != ACT_NONE:  # tanh'(pre) = 1 - y^2 ; (leaky) relu'(pre) has the sign of y
+            dy = act_bwd_raw(y, dy, act)
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -493,6 +493,69 @@ class SpatialMeanFn(torch.autograd.Function):
 
 def spatial_mean(x):
     return SpatialMeanFn.apply(x)
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    """F.max_pool2d(x, 2) on NHWC; the arg-max slot of every element is kept as a byte for the backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _req(x, "pool input")
+        N, H, W, Cn = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cn), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, H // 2, W // 2, Cn), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.load().mstg_maxpool2x2_fwd(_p(x), _p(y), _p(idx), N, H, W, Cn, _stream()), "mstg_maxpool2x2_fwd")
+        ctx.shape = (N, H, W, Cn)
+        ctx.save_for_backward(idx)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        (idx,) = ctx.saved_tensors
+        N, H, W, Cn = ctx.shape
+        dy = _req(dy, "pool grad_output")
+        dx = torch.zeros((N, H, W, Cn), dtype=torch.float32, device=dy.device) if (H & 1 or W & 1) else \
+            torch.empty((N, H, W, Cn), dtype=torch.float32, device=dy.device)
+        _lib.check(_lib.load().mstg_maxpool2x2_bwd(_p(dy), _p(idx), _p(dx), N, H, W, Cn, _stream()), "mstg_maxpool2x2_bwd")
+        return dx
+
+
+def maxpool2x2(x, return_indices=False):
+    y, idx = MaxPool2x2Fn.apply(x)
+    return (y, idx) if return_indices else y
+
+
+class GramFn(torch.autograd.Function):
+    """G[n] = F[n]^T F[n] / (C H W) for NHWC features (N,H,W,C) -> (N,C,C)."""
+
+    @staticmethod
+    def forward(ctx, f):
+        lib = _lib.load()
+        f = _req(f, "gram input")
+        N, H, W, Cn = f.shape
+        scale = 1.0 / (Cn * H * W)
+        g = torch.empty((N, Cn, Cn), dtype=torch.float32, device=f.device)
+        ws = _ws(lib.mstg_gram_workspace_bytes(N, H * W, Cn), f.device)
+        _timed("gram_fwd_kernel", 2.0 * N * H * W * Cn * Cn, 4.0 * (N * H * W * Cn + N * Cn * Cn), lambda: _lib.check(
+            lib.mstg_gram_fwd(_p(f), _p(g), N, H * W, Cn, scale, _p(ws), ws.numel() * 4, _stream()), "mstg_gram_fwd"))
+        ctx.scale = scale
+        ctx.save_for_backward(f)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (f,) = ctx.saved_tensors
+        dg = _req(dg, "gram grad_output")
+        N, H, W, Cn = f.shape
+        df = torch.empty_like(f)
+        _timed("gram_bwd_kernel", 2.0 * N * H * W * Cn * Cn, 4.0 * 2 * N * H * W * Cn, lambda: _lib.check(
+            _lib.load().mstg_gram_bwd(_p(f), _p(dg), _p(df), N, H * W, Cn, ctx.scale, _stream()), "mstg_gram_bwd"))
+        return df
+
+
+def gram_matrix(f):
+    return GramFn.apply(f)
 
 
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, mask=None):

@@ -284,3 +284,50 @@ def test_train_step_gradients_vs_oracle():
                 assert float(mine[i].abs().max()) == 0.0, n
         check_grads(f"train_step first-step {which}-gradients", [names[i] for i in keep], [mine[i] for i in keep],
                     [ref_list[i] for i in keep])
+
+
+def test_train_step_with_style_loss_vs_oracle():
+    """Extended step (build-defined multi-style Gram loss attached, parity unpinned vs the reference): generator gradients
+    against the oracle's autograd of the same definition."""
+    from oracle import restatement as R
+    C, shape, div = 8, (2, 3, 32, 32), 4  # Gram needs channel counts that are multiples of 16
+    # seeds of test_train_step_gradients_vs_oracle: a well-conditioned draw.  (With seeds 91-94 the CPU oracle in fp32 already
+    # differs from itself in fp64 by 2 % on some tensors -- ReLU masks flipping on 8x8 maps, tools/diag_style_step2.py.)
+    model, sds = _build_cyclegan(C, [81, 82, 83, 84])
+    refs = [R.make_input(shape, 95 + k) for k in range(3)]
+    model.attach_style_loss(refs, (0.5, 0.3, 0.2), lambda_style=3.0, width_div=div)
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in model.style_loss.features.state_dict().items()}
+    a, b = R.make_input(shape, 90), R.make_input(shape, 91)
+    captured = {}
+    model.g_optimizer.step = lambda: captured.__setitem__("g", model.g_optimizer.grad.clone())
+    model.d_optimizer.step = lambda: None
+    losses = model.train_step(a.to(DEV), b.to(DEV))
+    assert "style_loss" in losses and losses["style_loss"] > 0
+    # oracle: same step with the extra term on fake_A = G_BA(real_B)
+    g_ab = {k: v.clone().requires_grad_(True) for k, v in sds[0].items()}
+    g_ba = {k: v.clone().requires_grad_(True) for k, v in sds[1].items()}
+    d_a, d_b = {k: v.clone() for k, v in sds[2].items()}, {k: v.clone() for k, v in sds[3].items()}
+    fake_B, fake_A = R.generator_forward(g_ab, a), R.generator_forward(g_ba, b)
+    for sd_, inp in ((d_a, a), (d_b, b), (d_a, fake_A.detach()), (d_b, fake_B.detach())):  # D phase: 4 power iterations
+        R.discriminator_forward(sd_, inp)
+    idt = (R.l1(R.generator_forward(g_ba, a), a) + R.l1(R.generator_forward(g_ab, b), b)) * 2.0
+    fa, _ = R.discriminator_forward(d_a, fake_A)
+    fb, _ = R.discriminator_forward(d_b, fake_B)
+    gl = R.mse(fa, 1.0) + R.mse(fb, 1.0)
+    cyc = (R.l1(R.generator_forward(g_ba, fake_B), a) + R.l1(R.generator_forward(g_ab, fake_A), b)) * 10.0
+    _, ras = R.discriminator_forward(d_a, a)
+    _, fas = R.discriminator_forward(d_a, fake_A)
+    _, rbs = R.discriminator_forward(d_b, b)
+    _, fbs = R.discriminator_forward(d_b, fake_B)
+    st = (R.l1(ras, fas) + R.l1(rbs, fbs)) * 0.5
+    sty = R.multi_style_gram_loss(vgg_sd, fake_A, refs, [0.5, 0.3, 0.2]) * 3.0
+    names = [k for k in g_ab if not k.startswith("style_encoder")]
+    grads = torch.autograd.grad(gl + cyc + idt + st + sty, [g_ab[k] for k in names] + [g_ba[k] for k in names])
+    assert abs(losses["style_loss"] - float(sty)) <= 1e-4 * max(1.0, abs(float(sty)))
+    ours = captured["g"].cpu()
+    all_names = [n for m in (model.G_AB, model.G_BA) for n, _ in m.named_parameters()]
+    mine = {}
+    for off, p, n, idx in zip(model.g_optimizer.offsets, model.g_optimizer.params, all_names, range(len(all_names))):
+        mine[(idx >= len(all_names) // 2, n)] = ours[off:off + p.numel()].view(p.shape)
+    keys = [(False, k) for k in names] + [(True, k) for k in names]
+    check_grads("train_step + style loss g-gradients", [k for _, k in keys], [mine[k] for k in keys], list(grads))

@@ -363,3 +363,64 @@ def test_local_attention_fused_vs_oracle(N, H, W, C):
     report(f"fused attention {N}x{H}x{W} C={C} dx", rel_l2(nchw(gg[0]), gr[0]), 1e-4)
     for name, a, b in zip(("dWqkv", "dbqkv", "dWproj", "dbproj"), gg[1:], gr[1:]):
         report(f"fused attention {N}x{H}x{W} C={C} {name}", rel_l2(a, b), 1e-4)
+
+
+def test_maxpool_and_gram_vs_torch():
+    """Build-defined style-loss pieces (parity unpinned: no reference implementation): max-pool values AND arg-max indices are
+    bit-exact against torch, Gram forward/backward against a CPU einsum."""
+    from mstg_hip import ops
+    x = rnd((2, 16, 12, 20), 71)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = x[0, 0, 1, 0] = x[0, 0, 1, 1] = 0.25  # a 4-way tie: the first slot must win
+    xr = x.clone().requires_grad_(True)
+    yr, ir = F.max_pool2d(xr, 2, return_indices=True)
+    gy = rnd(tuple(yr.shape), 72)
+    (gxr,) = torch.autograd.grad((yr * gy).sum(), [xr])
+    xg = nhwc(x).to(DEV).requires_grad_(True)
+    yg, ig = ops.maxpool2x2(xg, return_indices=True)
+    (gxg,) = torch.autograd.grad((yg * nhwc(gy).to(DEV)).sum(), [xg])
+    assert torch.equal(nchw(yg).cpu(), yr.detach()), "max-pool values must be bit-exact"
+    oy, ox = torch.meshgrid(torch.arange(6), torch.arange(10), indexing="ij")
+    slot = nchw(ig).cpu().long()
+    flat = (2 * oy + slot // 2) * 20 + (2 * ox + slot % 2)
+    assert torch.equal(flat, ir), "arg-max indices must match torch exactly"
+    assert torch.equal(nchw(gxg).cpu(), gxr), "max-pool backward must be bit-exact"
+    for N, H, W, C in ((2, 8, 8, 16), (1, 32, 32, 64), (2, 16, 8, 128), (1, 128, 96, 32)):
+        f = rnd((N, C, H, W), 73 + C)
+        fr = f.clone().requires_grad_(True)
+        m = fr.reshape(N, C, H * W)
+        gr = torch.bmm(m, m.transpose(1, 2)) / (C * H * W)
+        w = rnd(tuple(gr.shape), 74)  # deliberately NOT symmetric: exercises dG + dG^T
+        (dfr,) = torch.autograd.grad((gr * w).sum(), [fr])
+        fg = nhwc(f).to(DEV).requires_grad_(True)
+        gg = ops.gram_matrix(fg)
+        (dfg,) = torch.autograd.grad((gg * w.to(DEV)).sum(), [fg])
+        report(f"gram {N}x{H}x{W} C={C} G", rel_l2(gg, gr), 2e-5)
+        report(f"gram {N}x{H}x{W} C={C} dF", rel_l2(nchw(dfg), dfr), 1e-4)
+
+
+def test_multi_style_loss_vs_oracle():
+    """VGG-topology features + weighted multi-reference Gram loss against the oracle's CPU restatement of the SAME
+    build-defined definition (parity unpinned against the reference: it has no such loss)."""
+    import style_loss
+    from oracle import restatement as R
+    div, shape = 4, (2, 3, 32, 48)
+    sd = R.make_state_dict(R.vgg_spec(div), 77)
+    feats = style_loss.VGGFeatures(width_div=div)
+    feats.load_state_dict(sd)
+    feats.to(DEV)
+    styles = [R.make_input(shape, 80 + k) for k in range(3)]
+    weights = (0.5, 0.3, 0.2)
+    y = R.make_input(shape, 90)
+    yr = y.clone().requires_grad_(True)
+    lr_ = R.multi_style_gram_loss(sd, yr, styles, list(weights))
+    (gyr,) = torch.autograd.grad(lr_, [yr])
+    loss_mod = style_loss.MultiStyleGramLoss(feats, [s.to(DEV) for s in styles], weights)
+    yg = y.to(DEV).requires_grad_(True)
+    fg = feats(yg)
+    fr = R.vgg_features(sd, y)
+    for l, (a, b) in enumerate(zip(fg, fr)):
+        report(f"vgg tap {l}", rel_l2(nchw(a), b), 2e-5)
+    lg = loss_mod(yg)
+    (gyg,) = torch.autograd.grad(lg, [yg])
+    report("multi-style loss value", abs(float(lg) - float(lr_)) / abs(float(lr_)), 1e-4)
+    report("multi-style loss d/dy", rel_l2(gyg, gyr), 1e-3)
