@@ -192,9 +192,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
             }
         }
         __syncthreads();
-        if (do_bias && tid < BN) {
+        if (do_bias && mode != MODE_DPACK && tid < BN) {
 #pragma unroll 8
             for (int p = 0; p < 128; ++p) bsum += ht[p * BNP + tid];
+        }
+        if (do_bias && mode == MODE_DPACK && tid < 4) {  // the tile's own 16 columns sit 3 pixels into the [8][htw][4] tile
+            for (int r = 0; r < WT_H; ++r)
+#pragma unroll 8
+                for (int c = 0; c < 16; ++c) bsum += ht[(r * a.htw + c + 3) * 4 + tid];
         }
         // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------------
         const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
@@ -662,8 +667,6 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient only for Conv2d (use mstg_channel_sum for ConvTranspose2d)");
     WGradArgs a{};
     if (int rc = fill_wgrad_args(d, x, dy, a)) return rc;
-    if (dbias && a.mode == MODE_DPACK)
-        return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad: fused bias gradient not available for <= 4 output channels (use mstg_channel_sum / mstg_plane_sum)");
     hipStream_t st = (hipStream_t)stream;
     a.partial = (float*)workspace;
     a.with_bias = dbias != nullptr;

@@ -191,7 +191,7 @@ class ConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             conv_dgrad_raw(d, dy, w, dx)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        fuse_db = want_db and ctx.needs_input_grad[1] and not transposed and Cout > 4  # <= 4: packed-column wgrad mode
+        fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             if fuse_db:
@@ -240,12 +240,8 @@ class MSBranchesFn(torch.autograd.Function):
                 conv_dgrad_raw(d, dy, ws[j], dx)
             dw = torch.empty_like(ws[j])
             d.accumulate = 0
-            if c4 > 4:
-                db = torch.empty(c4, dtype=torch.float32, device=dy.device)
-                conv_wgrad_raw(d, x, dy, dw, db)
-            else:  # <= 4 output channels: the wgrad kernel packs pixel shifts into its idle columns, bias summed apart
-                conv_wgrad_raw(d, x, dy, dw, None)
-                db = channel_sum(dy, N * H * W, 4 * c4, j * c4, c4)
+            db = torch.empty(c4, dtype=torch.float32, device=dy.device)
+            conv_wgrad_raw(d, x, dy, dw, db)
             grads += [dw, db]
         return (dx, *grads)
 
