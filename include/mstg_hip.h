@@ -96,7 +96,7 @@ int mstg_norm_act_bwd(const float* x, const float* stats, const float* dy, float
  *   q,k L2-normalised per pixel over channels (F.normalize, eps 1e-12) ; attn = softmax_c2(sum_p q^[p,c1] k^[p,c2])
  *   (C x C per window, no scale) ; o[p,c1] = sum_c2 attn[c1,c2] v[p,c2].
  * qkv: NHWC (N,H,W,3C) with q|k|v channel blocks (= qkv.chunk(3, dim=1)); o: NHWC (N,H,W,C).
- * H, W multiples of 4 (anything else raises in the reference too); C a multiple of 4, <= 64 in this build.
+ * H, W multiples of 4 (anything else raises in the reference too); C a multiple of 4, <= 256 (row-blocked above 64).
  * ---------------------------------------------------------------------------------------------- */
 int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int H, int W, int C, void* stream);
 /* dqkv from d_o; the attention matrix is recomputed from qkv, nothing but qkv is saved by the forward */

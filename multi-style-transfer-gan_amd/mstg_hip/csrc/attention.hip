@@ -540,11 +540,235 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
     return MSTG_OK;
 }
 
+// =====================================================================================================================
+// Row-blocked core for wide layers (64 < C <= 256: the class-default channels=64 generator has C_l = 128 and 256).  The
+// C x C attention matrix no longer fits on chip at once (256 KiB at C = 256), so it is produced 16 rows (c1) at a time:
+// softmax needs complete rows only, and everything that sums over c1 (dV, dk^) is accumulated across the row blocks in
+// registers.  One wave per window as before; LDS holds q^|k^|v, one 16 x C block of P / dS, dO and dq^.
+// =====================================================================================================================
+template <int CP>
+struct BlkTiles {
+    static constexpr int NF = CP / 16, LDQ = 3 * CP + 4, LDP = CP + 4;
+    static constexpr int QKV = 0, P = 16 * LDQ, INVN = P + 16 * LDP, END_FWD = INVN + 32;
+    static constexpr int DO = END_FWD, DQ = DO + 16 * LDP, DOTQ = DQ + 16 * LDP, END_BWD = DOTQ + 16;
+};
+
+// normalise q, k in place (tile [16][LDQ]) and leave 1/||.|| in invn[2][16]
+template <int CP>
+__device__ __forceinline__ void blk_normalise(float* qkv, float* invn, int lane) {
+    typedef BlkTiles<CP> T;
+    const int i = lane & 15, g = lane >> 4;
+    float sq = 0.f, sk = 0.f;
+    const int c0 = g * (CP / 4);
+    for (int c = c0; c < c0 + CP / 4; ++c) {
+        const float a = qkv[i * T::LDQ + c], b = qkv[i * T::LDQ + CP + c];
+        sq += a * a;
+        sk += b * b;
+    }
+    sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+    sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+    const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+    for (int c = c0; c < c0 + CP / 4; ++c) {
+        qkv[i * T::LDQ + c] *= iq;
+        qkv[i * T::LDQ + CP + c] *= ik;
+    }
+    if (g == 0) { invn[i] = iq; invn[16 + i] = ik; }
+}
+
+// P block (rows c1 in [16b, 16b+16)) -> registers (softmaxed) and LDS tile Ps[16][LDP]
+template <int CP>
+__device__ __forceinline__ void blk_softmax_rows(f32x4 (&s)[1][CP / 16], float* sm, int b, int C, int lane) {
+    typedef BlkTiles<CP> T;
+    constexpr int NF = T::NF;
+    const int i = lane & 15;
+    tile_zero<1, NF>(s);
+    tile_mma<1, NF>(s, sm + T::QKV + 16 * b, 1, T::LDQ, sm + T::QKV + CP, T::LDQ, 1, 16, lane);  // q^_blk^T k^
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            if (16 * nf + i >= C) s[0][nf][r] = -INFINITY;
+            mx = fmaxf(mx, s[0][nf][r]);
+        }
+        mx = row16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            s[0][nf][r] = __expf(s[0][nf][r] - mx);
+            sum += s[0][nf][r];
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) s[0][nf][r] *= inv;
+    }
+    tile_store<1, NF>(s, sm + T::P, T::LDP, 1, lane);
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void attn_core_fwd_blk_kernel(const float* __restrict__ qkv_g, float* __restrict__ o_g, int N, int H,
+                                                               int W, int C) {
+    typedef BlkTiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        load_window<CP>(qkv_g, sm + T::QKV, T::LDQ, 3, C, H, W, n, wy, wx, lane);
+        WAVE_SYNC();
+        blk_normalise<CP>(sm + T::QKV, sm + T::INVN, lane);
+        WAVE_SYNC();
+        const int y = 4 * wy + (i >> 2), x = 4 * wx + (i & 3);
+        float* dst = o_g + (((size_t)n * H + y) * W + x) * C;
+        for (int b = 0; 16 * b < C; ++b) {
+            f32x4 s[1][NF];
+            blk_softmax_rows<CP>(s, sm, b, C, lane);
+            WAVE_SYNC();
+            f32x4 o[1][1];  // O^T[c1 in block][p] = sum_c2 P[c1][c2] V[p][c2]
+            tile_zero<1, 1>(o);
+            tile_mma<1, 1>(o, sm + T::P, T::LDP, 1, sm + T::QKV + 2 * CP, 1, T::LDQ, CP, lane);
+            const int c = 16 * b + 4 * g;
+            if (c < C) *reinterpret_cast<f32x4*>(dst + c) = o[0][0];
+            WAVE_SYNC();
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(64) void attn_core_bwd_blk_kernel(const float* __restrict__ qkv_g, const float* __restrict__ do_g,
+                                                               float* __restrict__ dqkv_g, int N, int H, int W, int C) {
+    typedef BlkTiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    float* qkv = sm + T::QKV;
+    float* Ps = sm + T::P;
+    float* invn = sm + T::INVN;
+    float* dOs = sm + T::DO;
+    float* dQ = sm + T::DQ;     // raw dq^ [16][LDP]
+    float* dotq = sm + T::DOTQ; // per pixel sum_c1 q^ dq^
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        WAVE_SYNC();
+        load_window<CP>(qkv_g, qkv, T::LDQ, 3, C, H, W, n, wy, wx, lane);
+        load_window<CP>(do_g, dOs, T::LDP, 1, C, H, W, n, wy, wx, lane);
+        WAVE_SYNC();
+        blk_normalise<CP>(qkv, invn, lane);
+        WAVE_SYNC();
+        f32x4 dv[1][NF], dk[1][NF];  // accumulated over the row blocks: rows = pixels, columns = c2
+        tile_zero<1, NF>(dv);
+        tile_zero<1, NF>(dk);
+        float qdot[4] = {0.f, 0.f, 0.f, 0.f};  // lane (i, g): partial of sum_c1 q^[p][c1] dq^[p][c1] for p = 4g + r
+        for (int b = 0; 16 * b < C; ++b) {
+            f32x4 s[1][NF];
+            blk_softmax_rows<CP>(s, sm, b, C, lane);  // P rows of this block -> Ps
+            WAVE_SYNC();
+            f32x4 ds[1][NF];  // dP[c1 blk][c2] = sum_p dO[p][c1] V[p][c2]
+            tile_zero<1, NF>(ds);
+            tile_mma<1, NF>(ds, dOs + 16 * b, 1, T::LDP, qkv + 2 * CP, T::LDQ, 1, 16, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float dot = 0.f;
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) dot += s[0][nf][r] * ds[0][nf][r];
+                dot = row16_sum(dot);
+#pragma unroll
+                for (int nf = 0; nf < NF; ++nf) ds[0][nf][r] = s[0][nf][r] * (ds[0][nf][r] - dot);
+            }
+            // dV[p][c2] += sum_{c1 in blk} dO[p][c1] P[c1][c2]   (P still in Ps)
+            tile_mma<1, NF>(dv, dOs + 16 * b, T::LDP, 1, Ps, T::LDP, 1, 16, lane);
+            WAVE_SYNC();
+            tile_store<1, NF>(ds, Ps, T::LDP, 1, lane);  // Ps <- dS block
+            WAVE_SYNC();
+            // dq^[p][c1 in blk] = sum_c2 dS[c1][c2] k^[p][c2]
+            f32x4 d[1][1];
+            tile_zero<1, 1>(d);
+            tile_mma<1, 1>(d, qkv + CP, T::LDQ, 1, Ps, 1, T::LDP, CP, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = 4 * g + r;
+                dQ[p * T::LDP + 16 * b + i] = d[0][0][r];
+                qdot[r] += qkv[p * T::LDQ + 16 * b + i] * d[0][0][r];
+            }
+            // dk^[p][c2] += sum_{c1 in blk} dS[c1][c2] q^[p][c1]
+            tile_mma<1, NF>(dk, qkv + 16 * b, T::LDQ, 1, Ps, T::LDP, 1, 16, lane);
+            WAVE_SYNC();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = row16_sum(qdot[r]);
+            if (i == 0) dotq[4 * g + r] = t;
+        }
+        // dk = (dk^ - k^ (k^ . dk^)) / ||k||, written straight to global; dV likewise
+        const int y = 4 * wy + (i >> 2), x = 4 * wx + (i & 3);
+        (void)y; (void)x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = 4 * g + r;
+            float dot = 0.f;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) dot += qkv[p * T::LDQ + CP + 16 * nf + i] * dk[0][nf][r];
+            dot = row16_sum(dot);
+            const float inv = invn[16 + p];
+            const int py = 4 * wy + (p >> 2), px = 4 * wx + (p & 3);
+            float* dst = dqkv_g + (((size_t)n * H + py) * W + px) * 3 * C;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int c = 16 * nf + i;
+                if (c < C) {
+                    dst[C + c] = (dk[0][nf][r] - qkv[p * T::LDQ + CP + c] * dot) * inv;
+                    dst[2 * C + c] = dv[0][nf][r];
+                }
+            }
+        }
+        WAVE_SYNC();
+        // dq = (dq^ - q^ (q^ . dq^)) / ||q||
+        for (int e = lane; e < 16 * (CP / 4); e += 64) {
+            const int q4 = e % (CP / 4), p = e / (CP / 4);
+            if (4 * q4 < C) {
+                const float dot = dotq[p], inv = invn[p];
+                f32x4 v = *reinterpret_cast<const f32x4*>(&dQ[p * T::LDP + 4 * q4]);
+                const f32x4 h = *reinterpret_cast<const f32x4*>(&qkv[p * T::LDQ + 4 * q4]);
+                v = (v - h * dot) * inv;
+                const int py = 4 * wy + (p >> 2), px = 4 * wx + (p & 3);
+                *reinterpret_cast<f32x4*>(dqkv_g + (((size_t)n * H + py) * W + px) * 3 * C + 4 * q4) = v;
+            }
+        }
+    }
+}
+
+template <int CP>
+static int launch_attn_blk(bool bwd, const float* qkv, const float* d_o, float* out, int N, int H, int W, int C, hipStream_t st) {
+    typedef BlkTiles<CP> T;
+    const size_t lds = (size_t)(bwd ? T::END_BWD : T::END_FWD) * sizeof(float);
+    const int nwin = N * (H / 4) * (W / 4);
+    int grid = 256 * 4;
+    if (grid > nwin) grid = nwin;
+    static bool set_f = false, set_b = false;
+    bool& set = bwd ? set_b : set_f;
+    if (!set) {
+        hipError_t e = bwd ? hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_bwd_blk_kernel<CP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_fwd_blk_kernel<CP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_blk)");
+        set = true;
+    }
+    if (bwd) hipLaunchKernelGGL((attn_core_bwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
+    else hipLaunchKernelGGL((attn_core_fwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
+    MSTG_CHECK_LAUNCH("attn_core_blk_kernel");
+    return MSTG_OK;
+}
+
 static int attn_check(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "window_attn: empty tensor");
     if (H % 4 || W % 4) return fail_arg(MSTG_E_BADARG, "window_attn: H and W must be multiples of the 4x4 window");
     if (C % 4) return fail_arg(MSTG_E_ALIGN, "window_attn: C must be a multiple of 4");
-    if (C > 64) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn: C > 64 not implemented in this build");
+    if (C > 256) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn: C > 256 not implemented in this build");
     return MSTG_OK;
 }
 
@@ -581,7 +805,9 @@ extern "C" int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int 
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16) return launch_attn<16>(false, qkv, nullptr, o, N, H, W, C, st);
     if (C <= 32) return launch_attn<32>(false, qkv, nullptr, o, N, H, W, C, st);
-    return launch_attn<64>(false, qkv, nullptr, o, N, H, W, C, st);
+    if (C <= 64) return launch_attn<64>(false, qkv, nullptr, o, N, H, W, C, st);
+    if (C <= 128) return launch_attn_blk<128>(false, qkv, nullptr, o, N, H, W, C, st);
+    return launch_attn_blk<256>(false, qkv, nullptr, o, N, H, W, C, st);
 }
 
 extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C,
@@ -591,7 +817,9 @@ extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, flo
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16) return launch_attn<16>(true, qkv, d_o, dqkv, N, H, W, C, st);
     if (C <= 32) return launch_attn<32>(true, qkv, d_o, dqkv, N, H, W, C, st);
-    return launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    if (C <= 64) return launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    if (C <= 128) return launch_attn_blk<128>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    return launch_attn_blk<256>(true, qkv, d_o, dqkv, N, H, W, C, st);
 }
 
 extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32; }

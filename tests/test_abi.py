@@ -52,7 +52,7 @@ def test_host_side_validation(lib):
     d = ops.make_desc(1, 16, 16, 16, 32, 32, 8, 4, 2, 1, 1, transposed=1)
     assert lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d)) > 0
     assert lib.mstg_window_attn_core_fwd(1, 1, 1, 6, 8, 16, None) == -1                   # H not a multiple of 4
-    assert lib.mstg_window_attn_core_fwd(1, 1, 1, 8, 8, 128, None) == -5                  # C > 64 not in this build
+    assert lib.mstg_window_attn_core_fwd(1, 1, 1, 8, 8, 512, None) == -5                  # C > 256 not in this build
     assert lib.mstg_norm_workspace_bytes(2, 64 * 64, 16) > 0
     assert lib.mstg_adam_step_flat(1, 1, 1, 1, 4, 1e-3, 0.5, 0.999, 1e-8, 0, None, None) == -1  # step counts from 1
 

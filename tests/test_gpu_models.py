@@ -102,6 +102,33 @@ def test_generator_vs_reference_golden(gold_dir, tag, checkpointing):
     check_grads(f"G[{tag}] ckpt={int(checkpointing)}", ["dx"] + names, grads, [_t(g["dx"])] + [_t(g["d_" + k]) for k in names])
 
 
+def test_generator_default_width_vs_oracle():
+    """The class-default width (channels=64, enhanced_generator.py:107): LocalAttention at C = 64, 128, 256 takes the
+    row-blocked core above 64 channels.  Forward and every gradient against the oracle's autograd on the CPU."""
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    C, shape = 64, (1, 3, 32, 32)
+    sd = R.make_state_dict(R.generator_spec(C), 31)
+    m = eg.EnhancedGenerator(num_transformer_blocks=0)
+    assert m.initial[0].out_channels == C
+    m.load_state_dict(sd)
+    m.to(DEV)
+    x = R.make_input(shape, 32)
+    xg = x.to(DEV).requires_grad_(True)
+    y = m(xg)
+    names = [k for k, _ in m.named_parameters() if not k.startswith("style_encoder")]
+    params = [p for k, p in m.named_parameters() if not k.startswith("style_encoder")]
+    grads = torch.autograd.grad(y.abs().mean(), [xg] + params)
+    # The checker runs in fp64 here: at this width the fp32 CPU run itself sits 1.4e-2 from the exact gradients (one
+    # ReLU-mask flip near the input, tools/diag_grad_c64.py), so fp32-vs-fp32 would measure the checker's noise.
+    sd_r = {k: (v.double().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    xr = x.double().requires_grad_(True)
+    yr = R.generator_forward(sd_r, xr)
+    refs = torch.autograd.grad(yr.abs().mean(), [xr] + [sd_r[k] for k in names])
+    report("G[c64_32x32] out vs oracle(fp64)", rel_l2(y, yr.detach()), 1e-4)
+    check_grads("G[c64_32x32] vs oracle(fp64)", ["dx"] + names, grads, refs)
+
+
 def test_generator_no_grad_blocks1_eval_and_errors():
     """What the inference callers do: num_transformer_blocks=1, .eval(), torch.no_grad() (direct_transform.py:35-63)."""
     import enhanced_generator as eg

@@ -209,7 +209,7 @@ def _attn_core_ref(qkv, C):
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 8), (1, 4, 8, 16), (2, 16, 16, 16), (1, 16, 8, 32), (2, 8, 8, 64), (1, 64, 64, 16),
-                                     (1, 4, 4, 4), (1, 8, 8, 24), (1, 8, 4, 48)])
+                                     (1, 4, 4, 4), (1, 8, 8, 24), (1, 8, 4, 48), (2, 8, 8, 128), (1, 4, 8, 256), (1, 8, 4, 96), (1, 4, 4, 200)])
 def test_window_attention_core(N, H, W, C):
     from mstg_hip import ops
     qkv = rnd((N, 3 * C, H, W), 51 + C, 2.0)
