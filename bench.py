@@ -74,6 +74,19 @@ def cpu_baseline(channels: int, size: int):
                       f"{threads} torch threads, fp32"}
 
 
+def pmc_traffic(sym: str, args):
+    """HBM bytes per launch of `sym` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs,
+    read side doubled as the MI355X guide prescribes for gfx950; tools/gpu_refresh.sh + tools/pmc_traffic.py).  PMC
+    counters cannot be read from inside this process, so the figure is the one measured on the default workload and is
+    reported only when this run IS the default workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    default = args.batch == 32 and args.size == 256 and args.channels == 16 and not args.style_loss
+    if not default or not os.path.exists(path):
+        return None, None
+    t = json.load(open(path)).get(sym)
+    return (t["hbm_bytes"], "profiles/r01_pmc_traffic.json") if t else (None, None)
+
+
 def main():
     args = parse()
     from mstg_hip import dp, ops
@@ -143,6 +156,8 @@ def main():
             ach = r["bytes"] / sec / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"])
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(sym, args)
         roofline.update({"kernel": sym, "launches_per_step": r["launches"], "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                          "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2)})
 
