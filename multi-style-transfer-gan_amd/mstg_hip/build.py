@@ -32,7 +32,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-I", INCLUDE, "-I", CSRC,
+    extra = os.environ.get("MSTG_HIPCC_FLAGS", "").split()  # e.g. -DMSTG_STAMPS for tools/diag_stamps.py
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *extra, "-I", INCLUDE, "-I", CSRC,
            *sources(), "-o", LIB]
     if verbose:
         print("[mstg_hip.build]", " ".join(cmd), flush=True)

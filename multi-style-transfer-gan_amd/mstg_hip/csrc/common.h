@@ -68,6 +68,86 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// ---- batched, branch-free staging of pixel windows into LDS -------------------------------------------------------------
+// A staging loop written as "for each element: load, store to LDS" makes every wave wait out one global-memory round trip
+// per iteration (6-10 per tile for the windows of this library).  The helpers below issue four independent, UNCONDITIONAL
+// 16-byte loads per thread (an element outside the image reads offset 0 of the image and is zeroed at the LDS write), so a
+// window costs ceil(elements / 1024) round trips, and index arithmetic is 32-bit with multiply-high divisions.
+
+// n / d for n < 65536, 1 < d < 65536
+__host__ __device__ __forceinline__ unsigned magic_u32(unsigned d) { return 0xFFFFFFFFu / d + 1u; }
+
+// Window of an NHWC tensor: rows x cols pixels from (y0, x0), nq channel quads per pixel (nq_valid of them exist),
+// element (r, c, q) -> lds[(r * cols + c) * ckp + 4 * q].  img = first channel of pixel (0, 0) of the image; the image's
+// H * W * ctot must stay below 2^30 floats (checked by the host).  NB = loads in flight per thread.
+template <int NB>
+__device__ __forceinline__ void stage_window_batch(const float* __restrict__ img, float* __restrict__ lds, int total, int e0, int cols,
+                                                   int nq, unsigned m_cols, unsigned m_nq, int y0, int x0, int H, int W, int ctot,
+                                                   int nq_valid, int ckp, int tid) {
+    f32x4 v[NB];
+    int dst[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int e = e0 + 256 * k + tid;
+        const int p = nq == 1 ? e : (int)__umulhi((unsigned)e, m_nq);
+        const int q = e - p * nq;
+        const int r = (int)__umulhi((unsigned)p, m_cols), c = p - r * cols;
+        const int iy = y0 + r, ix = x0 + c;
+        ok[k] = e < total && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && q < nq_valid;
+        const unsigned off = ok[k] ? (unsigned)(iy * W + ix) * (unsigned)ctot + 4u * q : 0u;
+        v[k] = *reinterpret_cast<const f32x4*>(img + off);
+        dst[k] = e < total ? p * ckp + 4 * q : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (dst[k] >= 0) *reinterpret_cast<f32x4*>(&lds[dst[k]]) = ok[k] ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+__device__ __forceinline__ void stage_window(const float* __restrict__ img, float* __restrict__ lds, int rows, int cols, int nq,
+                                             unsigned m_cols, unsigned m_nq, int y0, int x0, int H, int W, int ctot, int nq_valid,
+                                             int ckp, int tid) {
+    const int total = rows * cols * nq;
+    int e0 = 0;
+    for (; e0 + 1024 < total; e0 += 2048)  // more than four elements per thread left: eight loads in flight
+        stage_window_batch<8>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid);
+    for (; e0 < total; e0 += 1024)
+        stage_window_batch<4>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid);
+}
+
+// Window of a tensor with at most 4 channels (any layout: sy / sx / sc = row / pixel / channel stride in floats),
+// pixel (r, c) -> the quad lds[(r * cols + c) * 4 ..], channels beyond nch zero.
+__device__ __forceinline__ void stage_window_c4(const float* __restrict__ img, float* __restrict__ lds, int rows, int cols,
+                                                unsigned m_cols, int y0, int x0, int H, int W, unsigned sy, unsigned sx, unsigned sc,
+                                                int nch, int tid) {
+    const int total = rows * cols;
+    for (int e0 = 0; e0 < total; e0 += 1024) {
+        f32x4 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + 256 * k + tid;
+            const int r = (int)__umulhi((unsigned)e, m_cols), c = e - r * cols;
+            const int iy = y0 + r, ix = x0 + c;
+            ok[k] = e < total && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const unsigned off = ok[k] ? (unsigned)iy * sy + (unsigned)ix * sx : 0u;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) v[k][ch] = img[off + (ch < nch ? ch * sc : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = e0 + 256 * k + tid;
+            if (e < total) {
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch)
+                    if (ok[k] && ch < nch) w[ch] = v[k][ch];
+                *reinterpret_cast<f32x4*>(&lds[e * 4]) = w;
+            }
+        }
+    }
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 

@@ -36,10 +36,21 @@ struct IGemmArgs {
     int ntaps;
     int act, accumulate;
     int dbg;
+    int TH;            // tile height in grid rows: 8, or 16 where the light kernel gives each wave four rows
     int dpack, tapsx;  // <= 4 output channels: rows of the MFMA tile = (pixel shift delta, channel), see igemm_light_kernel
 };
 
 constexpr int TILE_H = 8, TILE_W = 16;
+
+// Phase time stamps of sampled workgroups (tools/diag_stamps.py); compiled in only with -DMSTG_STAMPS.
+#ifdef MSTG_STAMPS
+__device__ unsigned long long g_dbg_stamps[64 * 8];
+#define MSTG_STAMP(k)                                                                                      \
+    if (threadIdx.x == 0 && (blockIdx.x % 251) == 0 && blockIdx.x / 251 < 64 && blockIdx.y == 0 && blockIdx.z == 0) \
+        g_dbg_stamps[(blockIdx.x / 251) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define MSTG_STAMP(k)
+#endif
 constexpr int W_BUDGET_FLOATS = 6144;  // 24 KiB of LDS for one tap group's filter slice
 
 template <int V> struct Frag;
@@ -99,12 +110,12 @@ __device__ __forceinline__ int tap_patch_offset(const IGemmArgs& a, int t, int p
 }
 
 // bias, optional accumulate, activation, store of one workgroup tile
-template <int NFW>
-__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, const f32x4 (&acc)[NFW][2], int n, int ty0, int tx0, int co0, int pa,
+template <int NFW, int PF = 2>
+__device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, const f32x4 (&acc)[NFW][PF], int n, int ty0, int tx0, int co0, int pa,
                                                int pb, int wave, int i, int g) {
 #pragma unroll
-    for (int pf = 0; pf < 2; ++pf) {
-        const int gy = ty0 * TILE_H + 2 * wave + pf, gx = tx0 * TILE_W + i;
+    for (int pf = 0; pf < PF; ++pf) {
+        const int gy = ty0 * (4 * PF) + PF * wave + pf, gx = tx0 * TILE_W + i;
         if (gy >= a.Gh || gx >= a.Gw) continue;
         const int oy = a.phase ? 2 * gy + pa : gy, ox = a.phase ? 2 * gx + pb : gx;
 #pragma unroll
@@ -142,14 +153,17 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmArgs& a, const f32x4 (
 // occupancy, not a deep per-workgroup pipeline.
 // V   : source channels per MFMA k-slot (a lane reads V consecutive channels; K chunk = 4V channels)
 // NFW : 16-channel output fragments per workgroup (BN = 16*NFW)
+// PF  : tile rows per wave (tile = 4*PF x 16 pixels).  Four rows halve, per pixel, everything a workgroup does once (index
+//       set-up, filter staging, halo) and reuse each filter fragment over four pixel fragments; two rows keep the patch small.
 // =====================================================================================================================
-template <int V, int NFW>
+template <int V, int NFW, int PF>
 __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, const float* __restrict__ wp, const int CoP) {
-    constexpr int CK = 4 * V, CKP = ckp_of<V>(), BN = 16 * NFW;
+    constexpr int CK = 4 * V, CKP = ckp_of<V>(), BN = 16 * NFW, TH = 4 * PF;
     typedef typename Frag<V>::T frag_t;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;
     float* wl = smem + ((a.PH * a.PW * CKP + 3) & ~3);
+    int* tapo = reinterpret_cast<int*>(wl + a.TG * BN * CKP);  // LDS offset of every tap inside the patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -157,39 +171,30 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
     const int co0 = blockIdx.y * BN;
     const int cls = blockIdx.z, pa = cls >> 1, pb = cls & 1;
     const int s = a.phase ? 1 : a.stride;
-    const int y0 = a.phase ? ty0 * TILE_H - 1 : ty0 * TILE_H * s - a.pad;
+    const int y0 = a.phase ? ty0 * TH - 1 : ty0 * TH * s - a.pad;
     // dpack: tiles advance by 13 output columns; the 16 accumulator columns start 3 pixels to their left
     const int x0 = a.phase ? tx0 * TILE_W - 1 : (a.dpack ? tx0 * 13 - 3 - a.pad : tx0 * TILE_W * s - a.pad);
     const int nchunks = (a.Cr + CK - 1) / CK;
+    const unsigned m_pw = magic_u32(a.PW);
+    MSTG_STAMP(0)
+    if (tid < a.ntaps) tapo[tid] = tap_patch_offset(a, tid, pa, pb, CKP);  // visible after the first barrier below
 
-    f32x4 acc[NFW][2];
+    f32x4 acc[NFW][PF];
 #pragma unroll
     for (int wf = 0; wf < NFW; ++wf)
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pf = 0; pf < PF; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         if (chunk) __syncthreads();
         // ---- stage the source patch (halo included, zero outside the image) -------------------------------------
         if (a.x_nchw) {  // 3-channel image tensor, V == 1: channel 3 of the k-slot group is zero
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int pc = lane; pc < a.PW; pc += 64) {
-                    const int ix = x0 + pc;
-                    const bool inb = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (inb) {
-                        const size_t base = (((size_t)n * a.x_ctot + a.x_coff) * a.H + iy) * a.W + ix;
-                        const size_t cs = (size_t)a.H * a.W;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < a.Cr) v[c] = a.x[base + c * cs];
-                    }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * CKP]) = v;
-                }
-            }
+            stage_window_c4(a.x + ((size_t)n * a.x_ctot + a.x_coff) * a.H * a.W, patch, a.PH, a.PW, m_pw, y0, x0, a.H, a.W, (unsigned)a.W, 1u,
+                            (unsigned)(a.H * a.W), a.Cr, tid);
+        } else if (((a.x_ctot | a.x_coff | a.Cr) & 3) == 0) {
+            stage_window(a.x + (size_t)n * a.H * a.W * a.x_ctot + a.x_coff + chunk * CK, patch, a.PH, a.PW, V, m_pw, 0xFFFFFFFFu / V + 1u, y0,
+                         x0, a.H, a.W, a.x_ctot, min(V, (a.Cr - chunk * CK) >> 2), CKP, tid);
         } else {
-            const bool al = ((a.x_ctot | a.x_coff) & 3) == 0;
             for (int pr = wave; pr < a.PH; pr += 4) {
                 const int iy = y0 + pr;
                 for (int e = lane; e < a.PW * V; e += 64) {
@@ -200,80 +205,111 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
                     const int c0 = chunk * CK + 4 * q;
                     if (inb && c0 < a.Cr) {
                         const float* src = a.x + (((size_t)n * a.H + iy) * a.W + ix) * a.x_ctot + a.x_coff + c0;
-                        if (al && c0 + 3 < a.Cr) {
-                            v = *reinterpret_cast<const f32x4*>(src);
-                        } else {
 #pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                if (c0 + c < a.Cr) v[c] = src[c];
-                        }
+                        for (int c = 0; c < 4; ++c)
+                            if (c0 + c < a.Cr) v[c] = src[c];
                     }
                     *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * CKP + 4 * q]) = v;
                 }
             }
         }
+        MSTG_STAMP(1)
         for (int t0 = 0; t0 < a.ntaps; t0 += a.TG) {
             __syncthreads();  // patch staged / previous tap group consumed
+            MSTG_STAMP(2)
             const int tn = min(a.TG, a.ntaps - t0);
             // ---- stage this tap group's filter slice: 16-byte copies out of the packed filter ---------------------
             const float* base = wp + ((size_t)((cls * nchunks + chunk) * a.ntaps + t0) * CoP + co0) * CK;
-            for (int e = tid; e < tn * BN * V; e += 256) {
-                const int row = e / V, q = e % V, tl = row / BN, col = row % BN;
-                *reinterpret_cast<f32x4*>(&wl[row * CKP + 4 * q]) =
-                    *reinterpret_cast<const f32x4*>(base + ((size_t)tl * CoP + col) * CK + 4 * q);
-            }
-            __syncthreads();
-            // ---- MFMA over the group's taps -------------------------------------------------------------------------
-            for (int tl = 0; tl < tn; ++tl) {
-                const int po = tap_patch_offset(a, t0 + tl, pa, pb, CKP);
-                frag_t af[NFW], bf[2];
+            for (int e0 = 0; e0 < tn * BN * V; e0 += 1024) {
+                f32x4 wv[4];
 #pragma unroll
-                for (int wf = 0; wf < NFW; ++wf)
-                    af[wf] = *reinterpret_cast<const frag_t*>(&wl[(tl * BN + 16 * wf + i) * CKP + V * g]);
-#pragma unroll
-                for (int pf = 0; pf < 2; ++pf) {
-                    const int r = 2 * wave + pf;
-                    bf[pf] = *reinterpret_cast<const frag_t*>(&patch[(r * s * a.PW + i * s) * CKP + po + V * g]);
+                for (int k = 0; k < 4; ++k) {
+                    const int e = min(e0 + 256 * k + tid, tn * BN * V - 1);
+                    const int row = e / V, q = e % V, tl = row / BN, col = row % BN;
+                    wv[k] = *reinterpret_cast<const f32x4*>(base + (unsigned)((tl * CoP + col) * CK + 4 * q));
                 }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = e0 + 256 * k + tid;
+                    if (e < tn * BN * V) *reinterpret_cast<f32x4*>(&wl[(e / V) * CKP + 4 * (e % V)]) = wv[k];
+                }
+            }
+            MSTG_STAMP(3)
+            __syncthreads();
+            MSTG_STAMP(4)
+            // ---- MFMA over the group's taps -------------------------------------------------------------------------
+            // fragments of tap tl+1 are read while the MFMAs of tap tl run
+            const int bbase0 = ((PF * wave) * s * a.PW + i * s) * CKP + V * g, bstep = s * a.PW * CKP;
+            frag_t af[NFW], bf[PF], afn[NFW], bfn[PF];
+            {
+                const int po = tapo[t0];
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) af[wf] = *reinterpret_cast<const frag_t*>(&wl[(16 * wf + i) * CKP + V * g]);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
+            }
+            for (int tl = 0; tl < tn; ++tl) {
+                const int tnx = min(tl + 1, tn - 1);
+                const int po = tapo[t0 + tnx];
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) afn[wf] = *reinterpret_cast<const frag_t*>(&wl[(tnx * BN + 16 * wf + i) * CKP + V * g]);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bfn[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
 #pragma unroll
                 for (int j = 0; j < V; ++j)
 #pragma unroll
                     for (int wf = 0; wf < NFW; ++wf)
 #pragma unroll
-                        for (int pf = 0; pf < 2; ++pf)
+                        for (int pf = 0; pf < PF; ++pf)
                             acc[wf][pf] = mfma16(frag_get<V>(af[wf], j), frag_get<V>(bf[pf], j), acc[wf][pf]);
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) af[wf] = afn[wf];
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = bfn[pf];
             }
         }
     }
+    MSTG_STAMP(5)
     if (!a.dpack) {
-        igemm_epilogue<NFW>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+        igemm_epilogue<NFW, PF>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+        MSTG_STAMP(6)
         return;
     }
     // ---- dpack epilogue.  Accumulator row 4*delta + c of pixel column p is a partial sum of output column p + delta:
     //      y[q][c] = sum_delta D[delta][q - delta].  Exchange through LDS, then lanes (q < 13, pf) finish 13 columns. ---------
     __syncthreads();  // everybody is done with the filter / patch tiles: reuse the front of LDS
-    float* comb = smem + wave * 512;  // [pf][delta][p][4]
+    float* comb = smem + wave * (256 * PF);  // [pf][delta][p][4]
 #pragma unroll
-    for (int pf = 0; pf < 2; ++pf) *reinterpret_cast<f32x4*>(&comb[((pf * 4 + g) * 16 + i) * 4]) = acc[0][pf];
+    for (int pf = 0; pf < PF; ++pf) *reinterpret_cast<f32x4*>(&comb[((pf * 4 + g) * 16 + i) * 4]) = acc[0][pf];
     __syncthreads();
-    if (g < 2 && i < 13) {
+    if (g < PF && i < 13) {
         const int pf = g;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int d = 0; d < 4; ++d) v += *reinterpret_cast<const f32x4*>(&comb[((pf * 4 + d) * 16 + i + 3 - d) * 4]);
-        const int oy = ty0 * TILE_H + 2 * wave + pf, ox = tx0 * 13 + i;
+        const int oy = ty0 * TH + PF * wave + pf, ox = tx0 * 13 + i;
         if (oy < a.Gh && ox < a.Gw) {
+            if (!a.y_nchw && a.Co == 4 && ((a.y_ctot | a.y_coff) & 3) == 0) {  // a whole 4-channel slice: one 16-byte store
+                float* p = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff;
+                if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias);
+                if (a.accumulate) v += *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (e >= a.Co) continue;
-                float* p = a.y_nchw ? a.y + (((size_t)n * a.y_ctot + a.y_coff + e) * a.Ho + oy) * a.Wo + ox
-                                    : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + e;
-                float val = v[e] + (a.bias ? a.bias[e] : 0.f);
-                if (a.accumulate) val += *p;
-                *p = apply_act(val, a.act);
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                *reinterpret_cast<f32x4*>(p) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e >= a.Co) continue;
+                    float* p = a.y_nchw ? a.y + (((size_t)n * a.y_ctot + a.y_coff + e) * a.Ho + oy) * a.Wo + ox
+                                        : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + e;
+                    float val = v[e] + (a.bias ? a.bias[e] : 0.f);
+                    if (a.accumulate) val += *p;
+                    *p = apply_act(val, a.act);
+                }
             }
         }
     }
+    MSTG_STAMP(6)
 }
 
 // =====================================================================================================================
@@ -488,32 +524,40 @@ __global__ __launch_bounds__(256) void igemm_heavy_kernel(const IGemmArgs a, con
 }
 
 struct IGemmPlan {
+    int pf;  // light kernel: tile rows per wave (2 or 4)
     int V, nfw, src, CK, CKP, BN, CoP, nchunks, ncls, TG, heavy;
     size_t lds, ws_bytes;
 };
 
-static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
+// tile / patch geometry for a tile height of th grid rows
+static void igemm_geometry(IGemmArgs& a, int th) {
+    a.TH = th;
     a.tiles_x = cdiv(a.Gw, TILE_W);
-    a.tiles_y = cdiv(a.Gh, TILE_H);
-    // <= 4 output channels (the RGB head, the stem's input gradient, the discriminator heads, 4-channel branches): pack four
-    // horizontally adjacent taps into the 16 filter rows of the MFMA tile instead of padding 4 channels to 16
-    a.dpack = !a.phase && a.Co <= 4 && a.stride == 1 && a.dil == 1 && a.KW > 1;
-    { const char* e = getenv("MSTG_NO_DPACK"); if (e && e[0] == '1') a.dpack = 0; }
+    a.tiles_y = cdiv(a.Gh, th);
     a.tapsx = cdiv(a.KW, 4);
     if (a.phase) {
-        a.PH = TILE_H + 2;
+        a.PH = th + 2;
         a.PW = TILE_W + 2;
         a.ntaps = 4;
     } else if (a.dpack) {
         a.tiles_x = cdiv(a.Gw, 13);
-        a.PH = (TILE_H - 1) + (a.KH - 1) + 1;
+        a.PH = (th - 1) + (a.KH - 1) + 1;
         a.PW = (TILE_W - 1) + 4 * a.tapsx;
         a.ntaps = a.KH * a.tapsx;
     } else {
-        a.PH = (TILE_H - 1) * a.stride + (a.KH - 1) * a.dil + 1;
+        a.PH = (th - 1) * a.stride + (a.KH - 1) * a.dil + 1;
         a.PW = (TILE_W - 1) * a.stride + (a.KW - 1) * a.dil + 1;
         a.ntaps = a.KH * a.KW;
     }
+}
+
+static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
+    // <= 4 output channels (the RGB head, the stem's input gradient, the discriminator heads, 4-channel branches): pack four
+    // horizontally adjacent taps into the 16 filter rows of the MFMA tile instead of padding 4 channels to 16
+    a.dpack = !a.phase && a.Co <= 4 && a.stride == 1 && a.dil == 1 && a.KW > 1;
+    { const char* e = getenv("MSTG_NO_DPACK"); if (e && e[0] == '1') a.dpack = 0; }
+    igemm_geometry(a, TILE_H);
+    p.pf = 2;
     if (a.N <= 0 || a.Gh <= 0 || a.Gw <= 0 || a.Co <= 0 || a.Cr <= 0) return fail_arg(MSTG_E_BADARG, "conv: empty tensor");
     if (a.x_nchw) {
         if (a.Cr > 4) return fail_arg(MSTG_E_UNSUPPORTED, "conv: NCHW source supports at most 4 channels");
@@ -544,15 +588,31 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
               lds_heavy <= 160 * 1024 && !(p.src == 2 && p.V != 1) && !(p.src == 0 && a.Cr < 4);
     // measured on MI355X: with the packed filter the high-occupancy kernel wins everywhere except on deep-channel layers
     // with few tiles (the discriminator's 32x32 / 16x16 maps), where a workgroup has too few neighbours to hide behind
-    p.heavy = p.heavy && a.Cr >= 64 && a.N * a.tiles_x * a.tiles_y * (p.CoP / p.BN) <= 1024;
-    { const char* e = getenv("MSTG_IGEMM"); if (e && e[0] == 'l') p.heavy = 0; }
+    {
+        const char* e = getenv("MSTG_IGEMM");
+        if (!(e && e[0] == 'h')) p.heavy = p.heavy && a.Cr >= 64 && a.N * a.tiles_x * a.tiles_y * (p.CoP / p.BN) <= 1024;
+        if (e && e[0] == 'l') p.heavy = 0;
+    }
     if (p.heavy) {
         p.TG = a.TG = tgh;
         p.lds = lds_heavy;
     } else {
+        // four rows per wave where the taller patch still leaves >= 3 workgroups per CU and the grid stays >= 4 per CU
+        {
+            const char* e = getenv("MSTG_PF");
+            const int force = e ? atoi(e) : 0;
+            const int ph16 = a.phase ? 18 : (a.dpack ? 15 + a.KH : 15 * a.stride + (a.KH - 1) * a.dil + 1);
+            const size_t lds16 = ((size_t)((ph16 * a.PW * p.CKP + 3) & ~3) + (size_t)tg * p.BN * p.CKP + 64) * sizeof(float);
+            const long blocks16 = (long)a.N * a.tiles_x * cdiv(a.Gh, 16) * (p.CoP / p.BN) * p.ncls;
+            if (force == 4 || (force != 2 && lds16 <= 52 * 1024 && blocks16 >= 1024 && a.Gh >= 16)) {
+                p.pf = 4;
+                igemm_geometry(a, 16);
+            }
+        }
+        const size_t patch_floats_l = (size_t)((a.PH * a.PW * p.CKP + 3) & ~3);
         p.TG = a.TG = tg;
-        p.lds = (patch_floats + (size_t)tg * p.BN * p.CKP) * sizeof(float);
-        if (a.dpack && p.lds < 4 * 512 * sizeof(float)) p.lds = 4 * 512 * sizeof(float);  // room for the shift-combine exchange
+        p.lds = (patch_floats_l + (size_t)tg * p.BN * p.CKP + 64) * sizeof(float);  // + tap-offset table (<= 64 taps)
+        if (a.dpack && p.lds < (size_t)4 * 256 * p.pf * sizeof(float)) p.lds = (size_t)4 * 256 * p.pf * sizeof(float);
         if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv: LDS patch too large for this geometry");
     }
     return MSTG_OK;
@@ -566,17 +626,17 @@ static int launch_pack(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t 
     return MSTG_OK;
 }
 
-template <int V, int NFW>
+template <int V, int NFW, int PF>
 static int launch_light_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_light_kernel<V, NFW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_light_kernel<V, NFW, PF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(igemm_light)");
         attr_set = true;
     }
     dim3 grid(a.N * a.tiles_x * a.tiles_y, p.CoP / p.BN, p.ncls);
-    hipLaunchKernelGGL((igemm_light_kernel<V, NFW>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    hipLaunchKernelGGL((igemm_light_kernel<V, NFW, PF>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
     MSTG_CHECK_LAUNCH("igemm_light_kernel");
     return MSTG_OK;
 }
@@ -593,7 +653,8 @@ static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
     // persistent workgroups: as many as fit on the chip at once (LDS / register bound), a multiple of 8 so that one
     // workgroup's tiles all fall into one XCD's contiguous run of the tile order (xcd_swizzle)
     const int ntiles = a.N * a.tiles_x * a.tiles_y, ny = p.CoP / p.BN, nz = p.ncls;
-    const int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
+    int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
+    { const char* e = getenv("MSTG_HEAVY_PER_CU"); if (e) per_cu = atoi(e); }
     int gx = (256 * per_cu) / (ny * nz);
     gx = gx < 8 ? 8 : (gx & ~7);
     if (gx > ntiles) gx = ntiles;
@@ -618,7 +679,8 @@ int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStrea
     if (int rc = launch_pack(a, p, wp, st)) return rc;
 #define MSTG_DISPATCH(VV, NN)                                                              \
     if (p.V == VV && p.nfw == NN) {                                                        \
-        if (!p.heavy) return launch_light_t<VV, NN>(a, p, wp, st);                         \
+        if (!p.heavy && p.pf == 4) return launch_light_t<VV, NN, 4>(a, p, wp, st);          \
+        if (!p.heavy) return launch_light_t<VV, NN, 2>(a, p, wp, st);                      \
         if (p.src == 0) return launch_heavy_t<VV, NN, 0>(a, p, wp, st);                    \
         if (p.src == 1) return launch_heavy_t<VV, NN, 1>(a, p, wp, st);                    \
         if (VV == 1 && p.src == 2) return launch_heavy_t<1, NN, 2>(a, p, wp, st);          \
@@ -648,6 +710,9 @@ int check_desc(const mstg_conv_desc* d) {
             return fail_arg(MSTG_E_UNSUPPORTED, "conv: strided convolution only as k4 s2 p1 on even H,W");
     }
     if (d->x_ctot < d->x_coff + d->Cin || d->y_ctot < d->y_coff + d->Cout) return fail_arg(MSTG_E_BADARG, "conv: channel slice out of range");
+    // the kernels index inside one image with 32-bit offsets (the image base is a 64-bit pointer)
+    if ((uint64_t)d->H * d->W * d->x_ctot >= (1ull << 30) || (uint64_t)d->Ho * d->Wo * d->y_ctot >= (1ull << 30))
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv: one image must stay below 2^30 elements");
     return MSTG_OK;
 }
 
@@ -735,10 +800,15 @@ const char* igemm_kernel_name(const mstg_conv_desc* d, int pass) {
     else if (fill_dgrad_args(d, a)) return "";
     if (plan_igemm(a, p)) return "";
     if (p.heavy) snprintf(name, sizeof(name), "igemm_heavy_kernel<%d, %d, %d>", p.V, p.nfw, p.src);
-    else snprintf(name, sizeof(name), "igemm_light_kernel<%d, %d>", p.V, p.nfw);
+    else snprintf(name, sizeof(name), "igemm_light_kernel<%d, %d, %d>", p.V, p.nfw, p.pf);
     return name;
 }
 
+#ifdef MSTG_STAMPS
+extern "C" int mstg_debug_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mstg::g_dbg_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
 extern "C" const char* mstg_version(void) { return "mstg-hip 0.1.0 gfx950"; }
 extern "C" const char* mstg_arch(void) { return "gfx950"; }
 extern "C" const char* mstg_last_error(void) { return mstg::g_last_error; }

@@ -53,6 +53,99 @@ struct WGradArgs {
 
 constexpr int WT_H = 8, WT_W = 16;
 
+// Stage one tile's gathered patch and grid-tensor tile into LDS (shared by both kernels).  The aligned NHWC cases and the
+// <= 4-channel cases go through the batched helpers of common.h; the rest (odd channel counts, wide NCHW) keeps simple loops.
+__device__ __forceinline__ void wgrad_stage(const WGradArgs& a, float* patch, float* ht, int n, int ty0, int gx0, int y0, int x0, int g0,
+                                            int h0, int TH, int nqh, int BNP, unsigned m_pw, unsigned m_htw, unsigned m_nqh, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, ckp = a.ckp, mode = a.mode;
+    const size_t gplane = (size_t)a.gH * a.gW, hplane = (size_t)a.hH * a.hW;
+    // ---- gathered patch, zero beyond Cg and outside the image ---------------------------------------------------------
+    if (mode == MODE_PACKX) {  // <= 4 channels, [row][col][4]
+        if (a.g_nchw)
+            stage_window_c4(a.g + ((size_t)n * a.g_ctot + a.g_coff) * gplane, patch, a.PH, a.PW, m_pw, y0, x0, a.gH, a.gW, a.gW, 1u,
+                            (unsigned)gplane, a.Cg, tid);
+        else
+            stage_window_c4(a.g + (size_t)n * gplane * a.g_ctot + a.g_coff, patch, a.PH, a.PW, m_pw, y0, x0, a.gH, a.gW,
+                            (unsigned)(a.gW * a.g_ctot), (unsigned)a.g_ctot, 1u, a.Cg, tid);
+    } else if (a.g_nchw) {
+        for (int pr = wave; pr < a.PH; pr += 4) {
+            const int iy = y0 + pr;
+            for (int pc = lane; pc < a.PW; pc += 64) {
+                const int ix = x0 + pc;
+                const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                float* dst = &patch[(pr * a.PW + pc) * ckp];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    float v = 0.f;
+                    if (inb && c < a.Cg) v = a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix];
+                    dst[c] = v;
+                }
+            }
+        }
+    } else if (((a.g_ctot | a.g_coff | a.Cg) & 3) == 0) {
+        stage_window(a.g + (size_t)n * gplane * a.g_ctot + a.g_coff + g0, patch, a.PH, a.PW, 4, m_pw, 0x40000000u, y0, x0, a.gH, a.gW,
+                     a.g_ctot, min(4, (a.Cg - g0) >> 2), ckp, tid);
+    } else {
+        for (int pr = wave; pr < a.PH; pr += 4) {
+            const int iy = y0 + pr;
+            for (int e = lane; e < a.PW * 4; e += 64) {
+                const int pc = e >> 2, q = e & 3;
+                const int ix = x0 + pc;
+                const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int c = g0 + 4 * q;
+                if (inb && c < a.Cg) {
+                    const float* src = a.g + (((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k < a.Cg) v[k] = src[k];
+                }
+                *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * ckp + 4 * q]) = v;
+            }
+        }
+    }
+    // ---- grid tensor tile, zero outside ------------------------------------------------------------------------------------
+    if (mode == MODE_DPACK) {  // <= 4 channels, [TH][htw][4], columns gx0 .. gx0 + htw
+        if (a.h_nchw)
+            stage_window_c4(a.h + ((size_t)n * a.h_ctot + a.h_coff) * hplane, ht, TH, a.htw, m_htw, ty0 * TH, gx0, a.hH, a.hW, a.hW, 1u,
+                            (unsigned)hplane, a.Ch, tid);
+        else if (a.Ch == 4 && ((a.h_ctot | a.h_coff) & 3) == 0)
+            stage_window(a.h + (size_t)n * hplane * a.h_ctot + a.h_coff, ht, TH, a.htw, 1, m_htw, 0u, ty0 * TH, gx0, a.hH, a.hW, a.h_ctot, 1,
+                         4, tid);
+        else
+            stage_window_c4(a.h + (size_t)n * hplane * a.h_ctot + a.h_coff, ht, TH, a.htw, m_htw, ty0 * TH, gx0, a.hH, a.hW,
+                            (unsigned)(a.hW * a.h_ctot), (unsigned)a.h_ctot, 1u, a.Ch, tid);
+    } else if (a.h_nchw) {
+        for (int c = wave; c < 4 * nqh; c += 4) {
+            for (int p = lane; p < TH * 16; p += 64) {
+                const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
+                float v = 0.f;
+                if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
+                    v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
+                ht[p * BNP + c] = v;
+            }
+        }
+    } else if (((a.h_ctot | a.h_coff | a.Ch) & 3) == 0) {
+        stage_window(a.h + (size_t)n * hplane * a.h_ctot + a.h_coff + h0, ht, TH, 16, nqh, 0x10000000u, m_nqh, ty0 * TH, gx0, a.hH, a.hW,
+                     a.h_ctot, min(nqh, (a.Ch - h0) >> 2), BNP, tid);
+    } else {
+        for (int e = tid; e < TH * 16 * nqh; e += 256) {
+            const int q = e % nqh, p = e / nqh;
+            const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int c = h0 + 4 * q;
+            if (gy < a.hH && gx < a.hW && c < a.Ch) {
+                const float* src = a.h + (((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + c;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < a.Ch) v[k] = src[k];
+            }
+            *reinterpret_cast<f32x4*>(&ht[p * BNP + 4 * q]) = v;
+        }
+    }
+}
+
+
 // TG  : accumulator fragments (taps) per workgroup z-slice;  NFH : 16-wide grid-channel fragments per workgroup
 template <int TG, int NFH>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
@@ -85,112 +178,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
 
     const bool do_bias = a.with_bias && gchunk == 0 && blockIdx.z == 0;
     float bsum = 0.f;  // thread c < BN: running column sum of grid channel h0 + c
+    const unsigned m_pw = magic_u32(a.PW), m_htw = magic_u32(a.htw);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int gx0 = tx0 * WT_W - a.xshift;  // first walked-grid column of this tile
         const int y0 = ty0 * WT_H * s - a.pad, x0 = gx0 * s - a.pad;
         __syncthreads();
-        // ---- stage the gathered patch, zero beyond Cg and outside the image -----------------------------------
-        if (mode == MODE_PACKX) {  // <= 4 channels, [row][col][4]
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int pc = lane; pc < a.PW; pc += 64) {
-                    const int ix = x0 + pc;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if ((unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < a.Cg)
-                                v[c] = a.g_nchw ? a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix]
-                                                : a.g[(((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c];
-                    }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * 4]) = v;
-                }
-            }
-        } else if (a.g_nchw) {
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int pc = lane; pc < a.PW; pc += 64) {
-                    const int ix = x0 + pc;
-                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
-                    float* dst = &patch[(pr * a.PW + pc) * ckp];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        float v = 0.f;
-                        if (inb && c < a.Cg) v = a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix];
-                        dst[c] = v;
-                    }
-                }
-            }
-        } else {
-            const bool al = ((a.g_ctot | a.g_coff) & 3) == 0;
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int e = lane; e < a.PW * 4; e += 64) {
-                    const int pc = e >> 2, q = e & 3;
-                    const int ix = x0 + pc;
-                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    const int c = g0 + 4 * q;
-                    if (inb && c < a.Cg) {
-                        const float* src = a.g + (((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c;
-                        if (al && c + 3 < a.Cg) {
-                            v = *reinterpret_cast<const f32x4*>(src);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (c + k < a.Cg) v[k] = src[k];
-                        }
-                    }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * ckp + 4 * q]) = v;
-                }
-            }
-        }
-        // ---- stage the grid tensor tile, zero outside -------------------------------------------------------------
-        if (mode == MODE_DPACK) {  // <= 4 channels, [8][htw][4], columns gx0 .. gx0 + htw
-            for (int e = tid; e < WT_H * a.htw; e += 256) {
-                const int r = e / a.htw, c = e % a.htw;
-                const int gy = ty0 * WT_H + r, gx = gx0 + c;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy < a.hH && (unsigned)gx < (unsigned)a.hW) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < a.Ch)
-                            v[k] = a.h_nchw ? a.h[(((size_t)n * a.h_ctot + a.h_coff + k) * a.hH + gy) * a.hW + gx]
-                                            : a.h[(((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + k];
-                }
-                *reinterpret_cast<f32x4*>(&ht[e * 4]) = v;
-            }
-        } else if (a.h_nchw) {
-            for (int c = wave; c < BN; c += 4) {
-                for (int p = lane; p < 128; p += 64) {
-                    const int gy = ty0 * WT_H + (p >> 4), gx = gx0 + (p & 15);
-                    float v = 0.f;
-                    if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
-                        v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
-                    ht[p * BNP + c] = v;
-                }
-            }
-        } else {
-            const bool al = ((a.h_ctot | a.h_coff) & 3) == 0;
-            for (int e = tid; e < 128 * (BN / 4); e += 256) {
-                const int q = e % (BN / 4), p = e / (BN / 4);
-                const int gy = ty0 * WT_H + (p >> 4), gx = gx0 + (p & 15);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                const int c = h0 + 4 * q;
-                if (gy < a.hH && gx < a.hW && c < a.Ch) {
-                    const float* src = a.h + (((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + c;
-                    if (al && c + 3 < a.Ch) {
-                        v = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (c + k < a.Ch) v[k] = src[k];
-                    }
-                }
-                *reinterpret_cast<f32x4*>(&ht[p * BNP + 4 * q]) = v;
-            }
-        }
+        wgrad_stage(a, patch, ht, n, ty0, gx0, y0, x0, g0, h0, WT_H, BN / 4, BNP, m_pw, m_htw, magic_u32(BN / 4), tid);
         __syncthreads();
         if (do_bias && mode != MODE_DPACK && tid < BN) {
 #pragma unroll 8
@@ -213,14 +207,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
 #pragma unroll
                 for (int hf = 0; hf < NFH; ++hf) bf[hf] = ht[r * hrow + c * hcol + 16 * hf + i];
                 const int abase = (r * s * a.PW + c * s) * ckp + i;
+                float af[TG];  // taps beyond tn repeat the last real tap: their accumulators are never written out
 #pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    if (t < tn) {
-                        const float af = patch[abase + toff[t]];
+                for (int t = 0; t < TG; ++t) af[t] = patch[abase + toff[t]];
 #pragma unroll
-                        for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = mfma16(af, bf[hf], acc[t][hf]);
-                    }
-                }
+                for (int t = 0; t < TG; ++t)
+#pragma unroll
+                    for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = mfma16(af[t], bf[hf], acc[t][hf]);
             }
         }
     }
@@ -316,114 +309,14 @@ __global__ __launch_bounds__(256) void wgrad_ts_kernel(const WGradArgs a, const 
 
     const bool do_bias = a.with_bias && gchunk == 0;
     float bsum = 0.f;  // thread c < 16*NFHT: running column sum of grid channel h0 + c
+    const unsigned m_pw = magic_u32(a.PW), m_htw = magic_u32(a.htw), m_nqh = magic_u32(4 * NFHT);
     const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int gx0 = tx0 * WT_W - a.xshift;
         const int y0 = ty0 * TH * s - a.pad, x0 = gx0 * s - a.pad;
         __syncthreads();
-        // ---- stage the gathered patch ------------------------------------------------------------------------------
-        if (mode == MODE_PACKX) {
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int pc = lane; pc < a.PW; pc += 64) {
-                    const int ix = x0 + pc;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if ((unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (c < a.Cg)
-                                v[c] = a.g_nchw ? a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix]
-                                                : a.g[(((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c];
-                    }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * 4]) = v;
-                }
-            }
-        } else if (a.g_nchw) {
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int pc = lane; pc < a.PW; pc += 64) {
-                    const int ix = x0 + pc;
-                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
-                    float* dst = &patch[(pr * a.PW + pc) * ckp];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        float v = 0.f;
-                        if (inb && c < a.Cg) v = a.g[(((size_t)n * a.g_ctot + a.g_coff + c) * a.gH + iy) * a.gW + ix];
-                        dst[c] = v;
-                    }
-                }
-            }
-        } else {
-            const bool al = ((a.g_ctot | a.g_coff) & 3) == 0;
-            for (int pr = wave; pr < a.PH; pr += 4) {
-                const int iy = y0 + pr;
-                for (int e = lane; e < a.PW * 4; e += 64) {
-                    const int pc = e >> 2, q = e & 3;
-                    const int ix = x0 + pc;
-                    const bool inb = (unsigned)iy < (unsigned)a.gH && (unsigned)ix < (unsigned)a.gW;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    const int c = g0 + 4 * q;
-                    if (inb && c < a.Cg) {
-                        const float* src = a.g + (((size_t)n * a.gH + iy) * a.gW + ix) * a.g_ctot + a.g_coff + c;
-                        if (al && c + 3 < a.Cg) {
-                            v = *reinterpret_cast<const f32x4*>(src);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (c + k < a.Cg) v[k] = src[k];
-                        }
-                    }
-                    *reinterpret_cast<f32x4*>(&patch[(pr * a.PW + pc) * ckp + 4 * q]) = v;
-                }
-            }
-        }
-        // ---- stage the grid tensor tile --------------------------------------------------------------------------------
-        if (mode == MODE_DPACK) {
-            for (int e = tid; e < TH * a.htw; e += 256) {
-                const int r = e / a.htw, c = e % a.htw;
-                const int gy = ty0 * TH + r, gx = gx0 + c;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (gy < a.hH && (unsigned)gx < (unsigned)a.hW) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (k < a.Ch)
-                            v[k] = a.h_nchw ? a.h[(((size_t)n * a.h_ctot + a.h_coff + k) * a.hH + gy) * a.hW + gx]
-                                            : a.h[(((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + k];
-                }
-                *reinterpret_cast<f32x4*>(&ht[e * 4]) = v;
-            }
-        } else if (a.h_nchw) {
-            for (int c = wave; c < 16 * NFHT; c += 4) {
-                for (int p = lane; p < TH * 16; p += 64) {
-                    const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
-                    float v = 0.f;
-                    if (gy < a.hH && gx < a.hW && h0 + c < a.Ch)
-                        v = a.h[(((size_t)n * a.h_ctot + a.h_coff + h0 + c) * a.hH + gy) * a.hW + gx];
-                    ht[p * BNP + c] = v;
-                }
-            }
-        } else {
-            const bool al = ((a.h_ctot | a.h_coff) & 3) == 0;
-            const int nq = 4 * NFHT;
-            for (int e = tid; e < TH * 16 * nq; e += 256) {
-                const int q = e % nq, p = e / nq;
-                const int gy = ty0 * TH + (p >> 4), gx = gx0 + (p & 15);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                const int c = h0 + 4 * q;
-                if (gy < a.hH && gx < a.hW && c < a.Ch) {
-                    const float* src = a.h + (((size_t)n * a.hH + gy) * a.hW + gx) * a.h_ctot + a.h_coff + c;
-                    if (al && c + 3 < a.Ch) {
-                        v = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (c + k < a.Ch) v[k] = src[k];
-                    }
-                }
-                *reinterpret_cast<f32x4*>(&ht[p * BNP + 4 * q]) = v;
-            }
-        }
+        wgrad_stage(a, patch, ht, n, ty0, gx0, y0, x0, g0, h0, TH, 4 * NFHT, BNP, m_pw, m_htw, m_nqh, tid);
         __syncthreads();
         if (do_bias && tid < 16 * NFHT) {
             for (int p = 0; p < TH * 16; ++p) bsum += ht[p * BNP + tid];
@@ -436,10 +329,11 @@ __global__ __launch_bounds__(256) void wgrad_ts_kernel(const WGradArgs a, const 
                 const int c = 4 * xs + g;
                 const int abase = (r * s * a.PW + c * s) * ckp + i;
                 const int hbase = r * hrow + c * hcol + i;
+                float af[UW], bf[UW];  // units beyond nu repeat the last real unit: their accumulators are never written out
 #pragma unroll
-                for (int k = 0; k < UW; ++k) {
-                    if (k < nu) acc[k] = mfma16(patch[abase + toff[k]], ht[hbase + hfo[k]], acc[k]);
-                }
+                for (int k = 0; k < UW; ++k) { af[k] = patch[abase + toff[k]]; bf[k] = ht[hbase + hfo[k]]; }
+#pragma unroll
+                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af[k], bf[k], acc[k]);
             }
         }
     }
@@ -508,10 +402,12 @@ struct WGradPlan {
 static WGradPlan plan_wgrad(const WGradArgs& a) {
     WGradPlan p;
     if (a.Teff == 1) p.tg = 1;
+    else if (a.Teff <= 3) p.tg = 3;
     else if (a.Teff <= 9) p.tg = 9;
+    else if (a.Teff == 14) p.tg = 14;
     else p.tg = 16;
     // 16 taps x 2 column fragments = 128 accumulator + 152 other registers = one wave per SIMD; one fragment keeps three
-    p.nfh = (a.mode == MODE_DPACK || a.Ch <= 16 || p.tg == 16) ? 1 : 2;
+    p.nfh = (a.mode == MODE_DPACK || a.Ch <= 16 || p.tg >= 14) ? 1 : 2;
     p.nz = cdiv(a.Teff, p.tg);
     p.TGn = cdiv(a.Teff, p.nz);
     const int ny = a.n_gchunks * (a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16 * p.nfh));
@@ -687,6 +583,9 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
         int rc = MSTG_E_UNSUPPORTED;
         if (p.tg == 1 && p.nfh == 1) rc = launch_wgrad_t<1, 1>(a, p, st);
         else if (p.tg == 1 && p.nfh == 2) rc = launch_wgrad_t<1, 2>(a, p, st);
+        else if (p.tg == 3 && p.nfh == 1) rc = launch_wgrad_t<3, 1>(a, p, st);
+        else if (p.tg == 3 && p.nfh == 2) rc = launch_wgrad_t<3, 2>(a, p, st);
+        else if (p.tg == 14 && p.nfh == 1) rc = launch_wgrad_t<14, 1>(a, p, st);
         else if (p.tg == 9 && p.nfh == 1) rc = launch_wgrad_t<9, 1>(a, p, st);
         else if (p.tg == 9 && p.nfh == 2) rc = launch_wgrad_t<9, 2>(a, p, st);
         else if (p.tg == 16 && p.nfh == 1) rc = launch_wgrad_t<16, 1>(a, p, st);

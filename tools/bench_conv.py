@@ -1,5 +1,5 @@
 """Micro-benchmark of single convolution passes through the C ABI (GPU box).  Usage:
-   python tools/bench_conv.py [filter-substring]
+   python tools/bench_conv.py [filter-substring] [fwd|dgrad|wgrad]
 Prints per case: ms, TFLOP/s (algorithmic), GB/s (algorithmic)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,7 @@ def timeit(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
+only = sys.argv[2] if len(sys.argv) > 2 else ""   # fwd | dgrad | wgrad
 dev = "cuda:0"
 for name, N, H, W, Cin, Cout, k, s_, p, d, tr, xn, yn in CASES:
     if filt and filt not in name: continue
@@ -50,5 +51,6 @@ for name, N, H, W, Cin, Cout, k, s_, p, d, tr, xn, yn in CASES:
     fl, by = ops._conv_cost(desc)
     for tag, fn in (("fwd", lambda: ops.conv_fwd_raw(desc, x, w, b, y)), ("dgrad", lambda: ops.conv_dgrad_raw(desc, dy, w, dx)),
                     ("wgrad", lambda: ops.conv_wgrad_raw(desc, x, dy, dw, None if (tr or Cout <= 4) else db))):
+        if only and only != tag: continue
         ms = timeit(fn)
         print(f"{name:22s} {tag:6s} {ms:8.3f} ms  {fl / ms / 1e9:7.2f} TFLOP/s  {by / ms / 1e6:8.1f} GB/s", flush=True)
