@@ -36,6 +36,7 @@ struct IGemmArgs {
     int ntaps;
     int act, accumulate;
     int dbg;
+    int psz;           // stream kernel: floats reserved for the LDS patch (>= the dpack exchange tiles)
     int TH;            // tile height in grid rows: 8, or 16 where the light kernel gives each wave four rows
     int dpack, tapsx;  // <= 4 output channels: rows of the MFMA tile = (pixel shift delta, channel), see igemm_light_kernel
 };
@@ -46,8 +47,8 @@ constexpr int TILE_H = 8, TILE_W = 16;
 #ifdef MSTG_STAMPS
 __device__ unsigned long long g_dbg_stamps[64 * 8];
 #define MSTG_STAMP(k)                                                                                      \
-    if (threadIdx.x == 0 && (blockIdx.x % 251) == 0 && blockIdx.x / 251 < 64 && blockIdx.y == 0 && blockIdx.z == 0) \
-        g_dbg_stamps[(blockIdx.x / 251) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && (blockIdx.x % 11) == 0 && blockIdx.x / 11 < 64 && blockIdx.y == 0 && blockIdx.z == 0) \
+        g_dbg_stamps[(blockIdx.x / 11) * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define MSTG_STAMP(k)
 #endif
@@ -313,6 +314,296 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
 }
 
 // =====================================================================================================================
+// "stream" kernel: the layers with few channels are bound by memory latency, not by MFMA or bandwidth (measured with
+// in-kernel time stamps: of a light workgroup's ~16k cycles, 7k wait for the patch, 1.5k for the filter, 2-3k for the
+// stores, and only 2-5k do MFMAs).  Here a workgroup is persistent and walks tiles with a stride of gridDim.x:
+//   * the WHOLE filter (all channel chunks and taps of this workgroup's output columns) is staged into LDS once;
+//   * a stage = (tile, channel chunk).  The loads of stage k+1's patch are issued into registers before stage k's MFMAs
+//     and written to the (single) LDS patch after them: the memory round trip runs under the MFMAs and the epilogue;
+//   * one LDS patch (not two) keeps three or more workgroups per CU, i.e. three patches permanently in flight per CU.
+// SRC : 0 = NHWC, aligned channel quads;  2 = NCHW tensor with <= 4 channels (V == 1).  NB patch slots per thread.
+// =====================================================================================================================
+constexpr int SNB = 8;
+
+template <int V, int NFW, int PF, int SRC>
+__global__ __launch_bounds__(256) void igemm_stream_kernel(const IGemmArgs a, const float* __restrict__ wp, const int CoP) {
+    constexpr int CK = 4 * V, CKP = ckp_of<V>(), BN = 16 * NFW, TH = 4 * PF;
+    typedef typename Frag<V>::T frag_t;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nchunks = (a.Cr + CK - 1) / CK;
+    const int wsz = nchunks * a.ntaps * BN * CKP;
+    float* patch = smem;
+    float* wl = smem + a.psz;
+    int* tapo = reinterpret_cast<int*>(wl + wsz);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int co0 = blockIdx.y * BN;
+    const int cls = blockIdx.z, pa = cls >> 1, pb = cls & 1;
+    const int s = a.phase ? 1 : a.stride;
+    const int ntiles = a.N * a.tiles_x * a.tiles_y;
+    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total = my_tiles * nchunks;
+    if (total == 0) return;
+
+    // ---- once: tap table, resident filter -----------------------------------------------------------------------------
+    if (tid < a.ntaps) tapo[tid] = tap_patch_offset(a, tid, pa, pb, CKP);
+    {
+        // packed filter wp[cls][chunk][tap][CoP][CK]  ->  wl[((chunk * ntaps + tap) * BN + col) * CKP + ci]
+        const int nrow = nchunks * a.ntaps * BN;  // rows of CK floats
+        const float* base = wp + (size_t)cls * nchunks * a.ntaps * CoP * CK + (size_t)co0 * CK;
+        for (int e0 = 0; e0 < nrow * V; e0 += 1024) {
+            f32x4 wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = min(e0 + 256 * k + tid, nrow * V - 1);
+                const int row = e / V, q = e % V, ct = row / BN, col = row % BN;
+                wv[k] = *reinterpret_cast<const f32x4*>(base + (unsigned)((ct * CoP + col) * CK + 4 * q));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = e0 + 256 * k + tid;
+                if (e < nrow * V) *reinterpret_cast<f32x4*>(&wl[(e / V) * CKP + 4 * (e % V)]) = wv[k];
+            }
+        }
+    }
+    // ---- per-thread patch slots (tile independent): element e = tid + 256 j  ->  (row, col, quad) -------------------
+    const int npatch = a.PH * a.PW * V;
+    const unsigned m_pw = magic_u32(a.PW);
+    int p_lds[SNB], p_rc[SNB];
+    unsigned p_off[SNB], used = 0;  // p_off: offset of the slot's element from the patch's first pixel (0 for unused slots)
+#pragma unroll
+    for (int j = 0; j < SNB; ++j) {
+        const int e = tid + 256 * j;
+        const int pp = e / V, q = e % V;
+        const int r = (int)__umulhi((unsigned)pp, m_pw), c = pp - r * a.PW;
+        const bool u = e < npatch;
+        p_lds[j] = u ? pp * CKP + 4 * q : -1;
+        p_rc[j] = r | (c << 8) | (q << 16);
+        p_off[j] = !u ? 0u : (SRC == 2 ? (unsigned)(r * a.W + c) : (unsigned)(r * a.W + c) * (unsigned)a.x_ctot + 4u * q);
+        used |= u ? (1u << j) : 0u;
+    }
+    const unsigned plane = (unsigned)(a.H * a.W);
+    // bias of this lane's output channels, once (the epilogue must not wait for a dependent global load per tile)
+    f32x4 breg[NFW];
+    unsigned cok = 0;  // bit wf: channels co0 + 16 wf + 4 g .. + 3 all exist
+#pragma unroll
+    for (int wf = 0; wf < NFW; ++wf) {
+        const int co = a.dpack ? 0 : co0 + 16 * wf + 4 * g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) breg[wf][e] = (a.bias && co + e < a.Co) ? a.bias[co + e] : 0.f;
+        cok |= (co + 3 < a.Co) ? (1u << wf) : 0u;
+    }
+    const bool yvec = !a.y_nchw && ((a.y_ctot | a.y_coff) & 3) == 0;
+    const int yrs = a.phase ? 2 * a.Wo : a.Wo, ycs = a.phase ? 2 : 1;  // output row / column step of the walked grid
+    const unsigned y_lane = (unsigned)((PF * wave) * yrs + i * ycs) * (unsigned)a.y_ctot + 4u * g;
+
+    // stage cursor -> (tile, chunk)
+    auto tile_of = [&](int seq, int& tx0, int& ty0, int& n) {
+        const int tile = xcd_swizzle((int)blockIdx.x + seq * (int)gridDim.x, ntiles);
+        tx0 = tile % a.tiles_x;
+        ty0 = (tile / a.tiles_x) % a.tiles_y;
+        n = tile / (a.tiles_x * a.tiles_y);
+    };
+    f32x4 preg[SNB];
+    unsigned pmask = 0;  // bit j: slot j holds a real (in-image, existing channel) element
+    auto load_stage = [&](int seq, int chunk) {
+        int tx0, ty0, n;
+        tile_of(seq, tx0, ty0, n);
+        const int y0 = a.phase ? ty0 * TH - 1 : ty0 * TH * s - a.pad;
+        const int x0 = a.phase ? tx0 * TILE_W - 1 : (a.dpack ? tx0 * 13 - 3 - a.pad : tx0 * TILE_W * s - a.pad);
+        pmask = 0;
+        const bool interior = y0 >= 0 && x0 >= 0 && y0 + a.PH <= a.H && x0 + a.PW <= a.W;  // wave-uniform
+        if (interior && SRC == 2) {
+            const float* base = a.x + ((size_t)n * a.x_ctot + a.x_coff) * plane + (unsigned)(y0 * a.W + x0);
+            pmask = used;
+#pragma unroll
+            for (int j = 0; j < SNB; ++j) {
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) preg[j][ch] = base[p_off[j] + (ch < a.Cr ? ch * plane : 0u)];
+            }
+        } else if (interior && SRC == 0 && (a.Cr - chunk * CK) >= CK) {
+            const float* base = a.x + ((size_t)n * plane + (unsigned)(y0 * a.W + x0)) * a.x_ctot + a.x_coff + chunk * CK;
+            pmask = used;
+#pragma unroll
+            for (int j = 0; j < SNB; ++j) preg[j] = *reinterpret_cast<const f32x4*>(base + p_off[j]);
+        } else if (SRC == 2) {
+            const float* img = a.x + ((size_t)n * a.x_ctot + a.x_coff) * plane;
+#pragma unroll
+            for (int j = 0; j < SNB; ++j) {
+                const int iy = y0 + (p_rc[j] & 255), ix = x0 + ((p_rc[j] >> 8) & 255);
+                const bool ok = p_lds[j] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(iy * a.W + ix) : 0u;
+                pmask |= ok ? (1u << j) : 0u;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) preg[j][ch] = img[off + (ch < a.Cr ? ch * plane : 0u)];
+            }
+        } else {
+            const float* img = a.x + (size_t)n * plane * a.x_ctot + a.x_coff + chunk * CK;
+            const int nqv = min(V, (a.Cr - chunk * CK) >> 2);
+#pragma unroll
+            for (int j = 0; j < SNB; ++j) {
+                const int iy = y0 + (p_rc[j] & 255), ix = x0 + ((p_rc[j] >> 8) & 255), q = p_rc[j] >> 16;
+                const bool ok = p_lds[j] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && q < nqv;
+                const unsigned off = ok ? (unsigned)(iy * a.W + ix) * (unsigned)a.x_ctot + 4u * q : 0u;
+                pmask |= ok ? (1u << j) : 0u;
+                preg[j] = *reinterpret_cast<const f32x4*>(img + off);
+            }
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < SNB; ++j) {
+            if (p_lds[j] >= 0) {
+                f32x4 v = preg[j];
+                if (!((pmask >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (SRC == 2) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        if (ch >= a.Cr) v[ch] = 0.f;
+                }
+                *reinterpret_cast<f32x4*>(&patch[p_lds[j]]) = v;
+            }
+        }
+    };
+
+    load_stage(0, 0);
+    store_stage();
+    __syncthreads();
+
+    f32x4 acc[NFW][PF];
+    int seq = 0, chunk = 0;
+    for (int k = 0; k < total; ++k) {
+        const bool more = k + 1 < total;
+        int nseq = seq, nchunk = chunk + 1;
+        if (nchunk == nchunks) { nchunk = 0; ++nseq; }
+        if (k == 2) { MSTG_STAMP(0) }
+        if (more) load_stage(nseq, nchunk);  // in flight during the MFMAs and the epilogue below
+        if (k == 2) { MSTG_STAMP(1) }
+        if (chunk == 0) {
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- MFMA over every tap of this chunk; fragments of tap t+1 are read while tap t's MFMAs run -----------------
+        {
+            const float* wc = wl + chunk * a.ntaps * BN * CKP;
+            const int bbase0 = ((PF * wave) * s * a.PW + i * s) * CKP + V * g, bstep = s * a.PW * CKP;
+            const int arow = i * CKP + V * g;
+            frag_t af[NFW], bf[PF], afn[NFW], bfn[PF];
+            {
+                const int po = tapo[0];
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) af[wf] = *reinterpret_cast<const frag_t*>(&wc[16 * wf * CKP + arow]);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
+            }
+            for (int t = 0; t < a.ntaps; ++t) {
+                const int tnx = min(t + 1, a.ntaps - 1);
+                const int po = tapo[tnx];
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) afn[wf] = *reinterpret_cast<const frag_t*>(&wc[(tnx * BN + 16 * wf) * CKP + arow]);
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bfn[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf)
+                            acc[wf][pf] = mfma16(frag_get<V>(af[wf], j), frag_get<V>(bf[pf], j), acc[wf][pf]);
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) af[wf] = afn[wf];
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = bfn[pf];
+            }
+        }
+        if (k == 2) { MSTG_STAMP(2) }
+        if (chunk == nchunks - 1) {
+            int tx0, ty0, n;
+            tile_of(seq, tx0, ty0, n);
+            if (!a.dpack && yvec && ty0 * TH + TH <= a.Gh && tx0 * TILE_W + TILE_W <= a.Gw) {
+                // whole tile inside the grid, 16-byte channel quads: no per-lane bounds work, bias from registers
+                const int oy0 = a.phase ? 2 * ty0 * TH + pa : ty0 * TH, ox0 = a.phase ? 2 * tx0 * TILE_W + pb : tx0 * TILE_W;
+                float* yb = a.y + (((size_t)n * a.Ho + oy0) * a.Wo + ox0) * a.y_ctot + a.y_coff + co0;
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) {
+#pragma unroll
+                    for (int wf = 0; wf < NFW; ++wf) {
+                        if ((cok >> wf) & 1u) {
+                            float* p = yb + y_lane + (unsigned)(pf * yrs * a.y_ctot + 16 * wf);
+                            f32x4 v = acc[wf][pf] + breg[wf];
+                            if (a.accumulate) v += *reinterpret_cast<const f32x4*>(p);
+                            if (a.act != MSTG_ACT_NONE) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                            }
+                            *reinterpret_cast<f32x4*>(p) = v;
+                        } else {
+                            const int co = co0 + 16 * wf + 4 * g;
+                            const int oy = oy0 + (PF * wave + pf) * (a.phase ? 2 : 1), ox = ox0 + i * ycs;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (co + e >= a.Co) continue;
+                                float* p = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + co + e;
+                                float val = acc[wf][pf][e] + breg[wf][e];
+                                if (a.accumulate) val += *p;
+                                *p = apply_act(val, a.act);
+                            }
+                        }
+                    }
+                }
+            } else if (!a.dpack) {
+                igemm_epilogue<NFW, PF>(a, acc, n, ty0, tx0, co0, pa, pb, wave, i, g);
+            } else {
+                // dpack: y[q][c] = sum_delta D[delta][q - delta] through an LDS exchange in the (now idle) patch area
+                __syncthreads();
+                float* comb = smem + wave * (256 * PF);  // [pf][delta][p][4]
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) *reinterpret_cast<f32x4*>(&comb[((pf * 4 + g) * 16 + i) * 4]) = acc[0][pf];
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's own exchange tile is complete (wave-private)
+                if (g < PF && i < 13) {
+                    const int pf = g;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) v += *reinterpret_cast<const f32x4*>(&comb[((pf * 4 + d) * 16 + i + 3 - d) * 4]);
+                    const int oy = ty0 * TH + PF * wave + pf, ox = tx0 * 13 + i;
+                    if (oy < a.Gh && ox < a.Gw) {
+                        v += breg[0];
+                        if (!a.y_nchw && a.Co == 4 && ((a.y_ctot | a.y_coff) & 3) == 0) {
+                            float* p = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff;
+                            if (a.accumulate) v += *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                            *reinterpret_cast<f32x4*>(p) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (e >= a.Co) continue;
+                                float* p = a.y_nchw ? a.y + (((size_t)n * a.y_ctot + a.y_coff + e) * a.Ho + oy) * a.Wo + ox
+                                                    : a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.y_ctot + a.y_coff + e;
+                                float val = v[e];
+                                if (a.accumulate) val += *p;
+                                *p = apply_act(val, a.act);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (k == 2) { MSTG_STAMP(3) }
+        __syncthreads();  // every wave is done with the patch (and the exchange tiles)
+        if (k == 2) { MSTG_STAMP(4) }
+        if (more) store_stage();
+        if (k == 2) { MSTG_STAMP(5) }
+        __syncthreads();
+        if (k == 2) { MSTG_STAMP(6) }
+        seq = nseq;
+        chunk = nchunk;
+    }
+}
+
+// =====================================================================================================================
 // "heavy" kernel: persistent workgroups with a software pipeline (issue-early / write-late).  A stage = (tile, channel
 // chunk, tap group).  While the MFMAs of stage k run, the global loads of stage k+1 (filter slice, and the source patch
 // when a new (tile, chunk) starts) are already in flight into registers; they are written to the OTHER half of the
@@ -524,7 +815,9 @@ __global__ __launch_bounds__(256) void igemm_heavy_kernel(const IGemmArgs a, con
 }
 
 struct IGemmPlan {
-    int pf;  // light kernel: tile rows per wave (2 or 4)
+    int pf;      // light / stream kernel: tile rows per wave (2 or 4)
+    int stream;  // persistent streaming kernel (filter resident in LDS, next patch prefetched into registers)
+    int gx;      // stream kernel: persistent workgroups along x
     int V, nfw, src, CK, CKP, BN, CoP, nchunks, ncls, TG, heavy;
     size_t lds, ws_bytes;
 };
@@ -558,6 +851,8 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     { const char* e = getenv("MSTG_NO_DPACK"); if (e && e[0] == '1') a.dpack = 0; }
     igemm_geometry(a, TILE_H);
     p.pf = 2;
+    p.stream = 0;
+    p.gx = 0;
     if (a.N <= 0 || a.Gh <= 0 || a.Gw <= 0 || a.Co <= 0 || a.Cr <= 0) return fail_arg(MSTG_E_BADARG, "conv: empty tensor");
     if (a.x_nchw) {
         if (a.Cr > 4) return fail_arg(MSTG_E_UNSUPPORTED, "conv: NCHW source supports at most 4 channels");
@@ -597,6 +892,39 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
         p.TG = a.TG = tgh;
         p.lds = lds_heavy;
     } else {
+        // ---- streaming kernel: aligned NHWC or <= 4-channel NCHW source, the whole filter of one workgroup resident in
+        //      LDS (<= 28 KiB), the patch within SNB slots per thread, >= 3 workgroups per CU ---------------------------------
+        p.stream = 0;
+        {
+            const char* e = getenv("MSTG_STREAM");
+            // Off by default: measured on MI355X (tools/diag_stamps.py) it wins only on the tap-heavy 16-channel layers
+            // (3x3 dilation 4: 0.165 -> 0.140 ms, 7x7 head: 0.278 -> 0.245 ms) and loses on the rest, because those layers are
+            // bound by the L2 -> CU traffic of the halo re-reads, not by the serialised phases.  MSTG_STREAM=1 enables it.
+            const bool allow = (e && e[0] == '1') && (p.src == 0 || (p.src == 2 && p.V == 1));
+            const size_t wsz = (size_t)p.nchunks * a.ntaps * p.BN * p.CKP;
+            const int ny = p.CoP / p.BN;
+            const char* epf = getenv("MSTG_PF");
+            const int force = epf ? atoi(epf) : 0;
+            for (int th = 16; allow && th >= 8 && !p.stream; th -= 8) {
+                if ((th == 16 && force == 2) || (th == 8 && force == 4)) continue;
+                if (a.Gh < th) continue;
+                igemm_geometry(a, th);
+                const int pf = th / 4;
+                size_t psz = (size_t)((a.PH * a.PW * p.CKP + 3) & ~3);
+                if (a.dpack && psz < (size_t)1024 * pf) psz = (size_t)1024 * pf;
+                const size_t lds = (psz + wsz + 64) * sizeof(float);
+                const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
+                int per_cu = (int)((160 * 1024) / lds);
+                if (per_cu > 6) per_cu = 6;
+                if (a.PH * a.PW * p.V > SNB * 256 || a.PH > 255 || a.PW > 255 || wsz * sizeof(float) > 28 * 1024 || per_cu < 3) continue;
+                int gx = (256 * per_cu) / (ny * p.ncls);
+                gx = gx < 8 ? 8 : (gx & ~7);
+                if (ntiles < 3L * gx && !(e && e[1] == 'f')) continue;  // a persistent workgroup needs a few tiles to pipeline ("1f" forces: tests)
+                p.stream = 1; p.pf = pf; p.gx = gx; a.psz = (int)psz; p.lds = lds;
+            }
+            if (!p.stream) igemm_geometry(a, TILE_H);
+        }
+        if (p.stream) return MSTG_OK;
         // four rows per wave where the taller patch still leaves >= 3 workgroups per CU and the grid stays >= 4 per CU
         {
             const char* e = getenv("MSTG_PF");
@@ -641,6 +969,21 @@ static int launch_light_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
     return MSTG_OK;
 }
 
+template <int V, int NFW, int PF, int SRC>
+static int launch_stream_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_stream_kernel<V, NFW, PF, SRC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(igemm_stream)");
+        attr_set = true;
+    }
+    dim3 grid(p.gx, p.CoP / p.BN, p.ncls);
+    hipLaunchKernelGGL((igemm_stream_kernel<V, NFW, PF, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_CHECK_LAUNCH("igemm_stream_kernel");
+    return MSTG_OK;
+}
+
 template <int V, int NFW, int SRC>
 static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
     static bool attr_set = false;
@@ -679,6 +1022,10 @@ int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStrea
     if (int rc = launch_pack(a, p, wp, st)) return rc;
 #define MSTG_DISPATCH(VV, NN)                                                              \
     if (p.V == VV && p.nfw == NN) {                                                        \
+        if (p.stream && p.src == 0 && p.pf == 4) return launch_stream_t<VV, NN, 4, 0>(a, p, wp, st); \
+        if (p.stream && p.src == 0) return launch_stream_t<VV, NN, 2, 0>(a, p, wp, st);   \
+        if (VV == 1 && p.stream && p.src == 2 && p.pf == 4) return launch_stream_t<1, NN, 4, 2>(a, p, wp, st); \
+        if (VV == 1 && p.stream && p.src == 2) return launch_stream_t<1, NN, 2, 2>(a, p, wp, st); \
         if (!p.heavy && p.pf == 4) return launch_light_t<VV, NN, 4>(a, p, wp, st);          \
         if (!p.heavy) return launch_light_t<VV, NN, 2>(a, p, wp, st);                      \
         if (p.src == 0) return launch_heavy_t<VV, NN, 0>(a, p, wp, st);                    \
@@ -799,7 +1146,8 @@ const char* igemm_kernel_name(const mstg_conv_desc* d, int pass) {
     if (pass == 0) fill_fwd_args(d, a);
     else if (fill_dgrad_args(d, a)) return "";
     if (plan_igemm(a, p)) return "";
-    if (p.heavy) snprintf(name, sizeof(name), "igemm_heavy_kernel<%d, %d, %d>", p.V, p.nfw, p.src);
+    if (p.stream) snprintf(name, sizeof(name), "igemm_stream_kernel<%d, %d, %d, %d>", p.V, p.nfw, p.pf, p.src);
+    else if (p.heavy) snprintf(name, sizeof(name), "igemm_heavy_kernel<%d, %d, %d>", p.V, p.nfw, p.src);
     else snprintf(name, sizeof(name), "igemm_light_kernel<%d, %d, %d>", p.V, p.nfw, p.pf);
     return name;
 }

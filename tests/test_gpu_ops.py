@@ -106,6 +106,35 @@ def test_conv_fwd_bwd(case):
     report(f"conv {name} db", rel_l2(gbg, gbr), 1e-4)
 
 
+STREAM_CASES = [
+    ("stream k3 d4 16->4", 2, 64, 80, 16, 4, 3, 1, 4, 4, 0, 0, 0, 0),
+    ("stream k3 d1 16->4 (dpack)", 2, 64, 80, 16, 4, 3, 1, 1, 1, 0, 0, 0, 0),
+    ("stream k3 d2 32->8 (two chunks)", 2, 48, 64, 32, 8, 3, 1, 2, 2, 0, 0, 0, 0),
+    ("stream head7x7 16->3 nchw-out tanh", 2, 64, 80, 16, 3, 7, 1, 3, 1, 0, 0, 1, 3),
+    ("stream stem7x7 3->16 nchw-in", 2, 64, 80, 3, 16, 7, 1, 3, 1, 0, 1, 0, 0),
+    ("stream 1x1 16->16", 2, 64, 80, 16, 16, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("stream convT 32->16", 2, 32, 40, 32, 16, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("stream k4s2 16->32 (dgrad by phases)", 2, 64, 80, 16, 32, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("stream ragged 37x53 16->20", 1, 37, 53, 16, 20, 3, 1, 1, 1, 0, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=[c[0] for c in STREAM_CASES])
+def test_conv_stream_kernel(case, monkeypatch):
+    """The opt-in persistent streaming igemm kernel (MSTG_STREAM=1; "1f" also lifts its minimum tile count) on the same
+    checks as the default kernels: interior fast path, border tiles, dpack exchange, channel chunks, parity classes."""
+    from mstg_hip import _lib
+    monkeypatch.setenv("MSTG_STREAM", "1f")
+    name, N, H, W, Cin, Cout, k, s, p, d, tr, x_nchw, y_nchw, act = case
+    Ho, Wo = (2 * H, 2 * W) if tr else ((H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1)
+    from mstg_hip import ops
+    desc = ops.make_desc(N, H, W, Cin, Ho, Wo, Cout, k, s, p, d, tr, x_nchw, y_nchw, act=act)
+    import ctypes
+    names = {_lib.load().mstg_conv2d_kernel_name(ctypes.byref(desc), ps).decode() for ps in (0, 1)}
+    assert any("stream" in n for n in names), names
+    test_conv_fwd_bwd(case)
+
+
 def test_conv_channel_slices_and_accumulate():
     """The multi-scale block's four branches: output into channel slices of one buffer, input gradients accumulated."""
     from mstg_hip import ops

@@ -10,6 +10,7 @@ lib = _lib.load()
 N, H, W, Cin, Cout, k, s_, p, d = 32, 256, 256, 16, 4, 3, 1, 4, 4
 if len(sys.argv) > 1 and sys.argv[1] == "d1": p, d = 1, 1
 if len(sys.argv) > 1 and sys.argv[1] == "1x1": Cout, k, p, d = 16, 1, 0, 1
+if len(sys.argv) > 1 and sys.argv[1] == "k7": Cout, k, p, d = 3, 7, 3, 1
 dev = "cuda:0"
 Ho, Wo = ops.conv_out_hw(H, W, k, s_, p, d, 0)
 x = torch.randn((N, H, W, Cin), device=dev); w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05; b = torch.randn(Cout, device=dev)
@@ -27,6 +28,7 @@ import statistics
 rows = [[buf[i * 8 + j] for j in range(7)] for i in range(64)]
 rows = [r for r in rows if r[0] and r[6] > r[0]]
 names = ["setup->patch staged", "->barrier1", "->filter staged", "->barrier2", "->mfma done", "->epilogue done"]
+if os.environ.get("MSTG_STREAM", "1") != "0": names = ["issue next loads", "mfma", "epilogue", "barrier A", "wait loads + LDS write", "barrier B"]
 print(f"{len(rows)} sampled workgroups; s_memtime ticks = shader cycles")
 for j in range(6):
     ds = [r[j + 1] - r[j] for r in rows]
