@@ -144,6 +144,15 @@ int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, float* dx, vo
 int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                         float eps, int step, const unsigned char* mask /*nullable: 0 = skip element*/, void* stream);
 
+/* torch.nn.utils.spectral_norm on a conv weight seen as an (M = Cout, K = Cin*kh*kw) matrix (enhanced_generator.py:269-271).
+ * fwd: training != 0 runs the one power iteration in place on u (M) and v (K); always sigma = u.(W v), w_out = w / sigma.
+ * bwd: dw = dwn / sigma - (sum(dwn * w) / sigma^2) u v^T with the u, v, sigma of that forward (the caller keeps copies:
+ * the next forward moves u and v on). */
+int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, int M, int K, float eps,
+                           int training, void* stream);
+int mstg_spectral_norm_bwd(const float* dwn, const float* w, const float* u, const float* v, const float* sigma, float* dw,
+                           int M, int K, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Build-defined multi-style perceptual loss pieces.  The reference has NO implementation of them (the
  * north star's "VGG-feature Gram-matrix / perceptual style loss" is a README bullet only) -- parity unpinned.

@@ -193,6 +193,8 @@ class EnhancedDiscriminator(nn.Module):
         for m in self.modules():  # reference :269-271 -- the hook recomputes W/sigma (one power iteration) per forward
             if isinstance(m, nn.Conv2d):
                 nn.utils.spectral_norm(m)
+                if os.environ.get("MSTG_TORCH_SPECTRAL_NORM", "0") != "1":
+                    ops.install_fused_spectral_norm(m)  # same parameters / buffers / state_dict; one launch instead of ~14
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mstg_gram_fwd": (_i, [_fp, _fp, _i, _i, _i, _f, _vp, _sz, _vp]),
     "mstg_gram_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _f, _vp]),
     "mstg_adam_step_flat": (_i, [_fp, _fp, _fp, _fp, _sz, _f, _f, _f, _f, _i, _vp, _vp]),
+    "mstg_spectral_norm_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _i, _vp]),
+    "mstg_spectral_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp]),
 }
 
 _lib = None

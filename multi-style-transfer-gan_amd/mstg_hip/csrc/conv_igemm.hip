@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
 #pragma unroll
                 for (int pf = 0; pf < PF; ++pf) bf[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
             }
-            for (int tl = 0; tl < tn; ++tl) {
+            for (int tl = 0; tl < ((a.dbg & 1) ? 1 : tn); ++tl) {
                 const int tnx = min(tl + 1, tn - 1);
                 const int po = tapo[t0 + tnx];
 #pragma unroll
@@ -1017,6 +1017,8 @@ int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStrea
     a.dbg = 0;
     IGemmPlan p;
     if (int rc = plan_igemm(a, p)) return rc;
+    { const char* e = getenv("MSTG_DBG"); if (e) a.dbg = atoi(e); }                       // experiments only: bit 0 = one tap only
+    { const char* e = getenv("MSTG_DBG_LDS_KB"); if (e && !p.heavy) p.lds += (size_t)atoi(e) * 1024; }  // lower the occupancy
     if (!workspace || workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv: workspace too small for the packed filter");
     float* wp = (float*)workspace;
     if (int rc = launch_pack(a, p, wp, st)) return rc;

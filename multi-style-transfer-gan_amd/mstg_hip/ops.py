@@ -554,6 +554,59 @@ def gram_matrix(f):
     return GramFn.apply(f)
 
 
+class SpectralNormFn(torch.autograd.Function):
+    """weight_orig -> weight_orig / sigma with torch.nn.utils.spectral_norm's semantics (one power iteration per
+    training-mode call, in place on the module's weight_u / weight_v buffers; u, v constants for autograd)."""
+
+    @staticmethod
+    def forward(ctx, w, u, v, eps, training):
+        w = _req(w, "spectral_norm weight")
+        u, v = _req(u, "spectral_norm u"), _req(v, "spectral_norm v")
+        M = w.shape[0]
+        K = w.numel() // M
+        if u.numel() != M or v.numel() != K:
+            raise RuntimeError(f"mstg_hip spectral_norm: u/v sizes {u.numel()}/{v.numel()} do not match weight {tuple(w.shape)}")
+        out = torch.empty_like(w)
+        sigma = torch.empty(1, dtype=torch.float32, device=w.device)
+        _lib.check(_lib.load().mstg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(out), _p(sigma), M, K, float(eps), int(bool(training)),
+                                                      _stream()), "mstg_spectral_norm_fwd")
+        # the buffers move on at the next forward; this call's backward needs the values it produced
+        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        ctx.dims = (M, K)
+        return out
+
+    @staticmethod
+    def backward(ctx, dwn):
+        w, u, v, sigma = ctx.saved_tensors
+        M, K = ctx.dims
+        dwn = _req(dwn, "spectral_norm grad_output")
+        dw = torch.empty_like(w)
+        _lib.check(_lib.load().mstg_spectral_norm_bwd(_p(dwn), _p(w), _p(u), _p(v), _p(sigma), _p(dw), M, K, _stream()),
+                   "mstg_spectral_norm_bwd")
+        return dw, None, None, None, None
+
+
+def install_fused_spectral_norm(module, name: str = "weight") -> bool:
+    """Swap the forward pre-hook that torch.nn.utils.spectral_norm registered on `module` for one that computes the same
+    thing in one launch (SpectralNormFn).  Parameters / buffers (`weight_orig`, `weight_u`, `weight_v`) and the state_dict
+    hooks stay torch's, so checkpoints are unchanged (enhanced_generator.py:269-271)."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    for key, hook in list(module._forward_pre_hooks.items()):
+        if isinstance(hook, SpectralNorm) and hook.name == name:
+            if hook.n_power_iterations != 1 or hook.dim != 0:
+                return False
+            eps = float(hook.eps)
+            del module._forward_pre_hooks[key]
+
+            def pre(mod, inputs, _eps=eps, _name=name):
+                setattr(mod, _name, SpectralNormFn.apply(getattr(mod, _name + "_orig"), getattr(mod, _name + "_u"),
+                                                         getattr(mod, _name + "_v"), _eps, mod.training))
+
+            module.register_forward_pre_hook(pre)
+            return True
+    return False
+
+
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, mask=None):
     _lib.check(_lib.load().mstg_adam_step_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step), _p(mask),
                                                _stream()), "mstg_adam_step_flat")

@@ -135,6 +135,35 @@ def test_conv_stream_kernel(case, monkeypatch):
     test_conv_fwd_bwd(case)
 
 
+@pytest.mark.parametrize("shape", [(16, 3, 4, 4), (128, 64, 4, 4), (128, 128, 3, 3), (1, 128, 4, 4), (24, 8, 1, 1)])
+def test_spectral_norm_fused_vs_torch(shape):
+    """One-launch spectral norm against torch.nn.utils.spectral_norm on the CPU: normalised weight, sigma path gradient,
+    and the evolution of weight_u / weight_v over three training-mode forwards and one eval-mode forward."""
+    import torch.nn as nn
+    from mstg_hip import ops
+    torch.manual_seed(sum(shape))
+    ref = nn.utils.spectral_norm(nn.Conv2d(shape[1], shape[0], (shape[2], shape[3])))
+    w0, u0, v0 = ref.weight_orig.detach().clone(), ref.weight_u.clone(), ref.weight_v.clone()
+    w = w0.to(DEV).requires_grad_(True)
+    u, v = u0.to(DEV), v0.to(DEV)
+    x = rnd((2, shape[1], shape[2] + 3, shape[3] + 3), 5)
+    for it in range(4):
+        training = it < 3
+        ref.train(training)
+        ref.zero_grad()
+        y = ref(x)
+        gy = rnd(tuple(y.shape), 6 + it)
+        (y * gy).sum().backward()
+        wn_ref, dw_ref = ref.weight.detach(), ref.weight_orig.grad
+        wn = ops.SpectralNormFn.apply(w, u, v, 1e-12, training)
+        yr = F.conv2d(x.to(DEV), wn, ref.bias.detach().to(DEV))
+        (dw,) = torch.autograd.grad((yr * gy.to(DEV)).sum(), [w])
+        report(f"spectral_norm {shape} it{it} weight", rel_l2(wn, wn_ref), 1e-5)
+        report(f"spectral_norm {shape} it{it} u", rel_l2(u, ref.weight_u), 1e-5)
+        report(f"spectral_norm {shape} it{it} v", rel_l2(v, ref.weight_v), 1e-5)
+        report(f"spectral_norm {shape} it{it} dweight_orig", rel_l2(dw, dw_ref), 1e-4)
+
+
 def test_conv_channel_slices_and_accumulate():
     """The multi-scale block's four branches: output into channel slices of one buffer, input gradients accumulated."""
     from mstg_hip import ops
