@@ -144,6 +144,15 @@ int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, float* dx, vo
 int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                         float eps, int step, const unsigned char* mask /*nullable: 0 = skip element*/, void* stream);
 
+/* MultiScaleBlock (enhanced_generator.py:52-71,79-83): weight and bias gradients of the four branch convolutions
+ * (1x1, 3x3 d1, 3x3 d2, 3x3 d4; each CH -> CH/4) in ONE pass over x (N,H,W,CH) and dy (N,H,W,CH = the four branch outputs
+ * concatenated).  dw1 (CH/4,CH,1,1), dw2..4 (CH/4,CH,3,3), db1..4 (CH/4), PyTorch layouts.  CH in {16, 32, 64}
+ * (mstg_msblock_fused_supported); other widths use mstg_conv2d_wgrad per branch. */
+int mstg_msblock_fused_supported(int CH);
+size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH);
+int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                       float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);
+
 /* torch.nn.utils.spectral_norm on a conv weight seen as an (M = Cout, K = Cin*kh*kw) matrix (enhanced_generator.py:269-271).
  * fwd: training != 0 runs the one power iteration in place on u (M) and v (K); always sigma = u.(W v), w_out = w / sigma.
  * bwd: dw = dwn / sigma - (sum(dwn * w) / sigma^2) u v^T with the u, v, sigma of that forward (the caller keeps copies:

@@ -1,0 +1,195 @@
+// MultiScaleBlock branch convolutions (enhanced_generator.py:52-71,79-83), fused across the four branches.
+//
+// The block runs a 1x1 and three dilated 3x3 convolutions (dilation 1, 2, 4), each ch -> ch/4, on the SAME input and
+// concatenates the results.  As four separate weight-gradient launches the input is staged four times (with four different
+// halos) and each launch pads its ch/4 output-gradient channels to a 16-wide MFMA fragment.  Seen together the four branches
+// are ONE sparse 9x9-footprint convolution with 25 distinct tap offsets: the centre (shared by all four branches) and three
+// rings of eight.  Here one workgroup stages the input patch (halo 4) and the full output-gradient tile once and accumulates
+// all 25 taps:
+//   GEMM view: M = 16 input channels (one chunk per blockIdx.y), N = the 16-channel fragment of dy the tap's branch lives in,
+//   K = pixels.  A "unit" = (tap, fragment): the centre tap needs every fragment (ch/16 units), a ring tap only its branch's
+//   fragment (24 units).  Units are dealt round-robin to the four waves; every wave walks all pixels of the tile for its own
+//   units (no cross-wave reduction).  Per-workgroup partial slabs are reduced in a fixed order by a second kernel, which also
+//   scatters the accumulators into the four PyTorch-layout weight gradients and the four bias gradients.
+#include "common.h"
+
+namespace mstg {
+
+constexpr int MS_TH = 8, MS_PH = MS_TH + 8, MS_PW = 16 + 8, MS_CKP = 20;
+
+template <int CH>
+__global__ __launch_bounds__(256) void wgrad_ms_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ partial, int N, int H, int W, int tiles_x, int tiles_y,
+                                                       int ntiles) {
+    constexpr int NFH = CH / 16, C4 = CH / 4, U = NFH + 24, UW = (U + 3) / 4, BNP = CH + 4, NG = CH / 16;
+    constexpr int PSTRIDE = NG * U * 256 + CH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                              // [PH][PW][CKP]   16 input channels of this chunk
+    float* ht = smem + MS_PH * MS_PW * MS_CKP;        // [TH*16][BNP]    all CH output-gradient channels
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int gchunk = blockIdx.y, g0 = 16 * gchunk;
+
+    f32x4 acc[UW];
+    int toff[UW], hfo[UW];
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        const int u = min(wave + 4 * k, U - 1);
+        int dyp = 0, dxp = 0, frag = u;  // centre tap: fragment u
+        if (u >= NFH) {
+            const int r = (u - NFH) >> 3, i8 = (u - NFH) & 7, t9 = i8 < 4 ? i8 : i8 + 1, d = 1 << r;
+            dyp = (t9 / 3 - 1) * d;
+            dxp = (t9 % 3 - 1) * d;
+            frag = ((r + 1) * C4) / 16;
+        }
+        toff[k] = ((4 + dyp) * MS_PW + 4 + dxp) * MS_CKP;
+        hfo[k] = 16 * frag;
+        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nu = (U - wave + 3) / 4;  // units this wave really owns
+
+    const bool do_bias = gchunk == 0;
+    float bsum = 0.f;  // thread c < CH: running column sum of dy channel c
+    const unsigned m_pw = magic_u32(MS_PW), m_nq = magic_u32(CH / 4);
+    const size_t plane = (size_t)H * W;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        __syncthreads();
+        stage_window(x + (size_t)n * plane * CH + g0, patch, MS_PH, MS_PW, 4, m_pw, 0x40000000u, ty0 * MS_TH - 4, tx0 * 16 - 4, H, W, CH, 4,
+                     MS_CKP, tid);
+        stage_window(dy + (size_t)n * plane * CH, ht, MS_TH, 16, CH / 4, 0x10000000u, m_nq, ty0 * MS_TH, tx0 * 16, H, W, CH, CH / 4, BNP, tid);
+        __syncthreads();
+        if (do_bias && tid < CH) {
+#pragma unroll 8
+            for (int p = 0; p < MS_TH * 16; ++p) bsum += ht[p * BNP + tid];
+        }
+#pragma unroll 1
+        for (int r = 0; r < MS_TH; ++r) {
+#pragma unroll 2
+            for (int xs = 0; xs < 4; ++xs) {
+                const int c = 4 * xs + g;  // this lane's k-slot pixel column
+                const int abase = (r * MS_PW + c) * MS_CKP + i;
+                const int hbase = (r * 16 + c) * BNP + i;
+                float af[UW], bf[UW];  // units beyond nu repeat the last real unit: their accumulators are never written out
+#pragma unroll
+                for (int k = 0; k < UW; ++k) { af[k] = patch[abase + toff[k]]; bf[k] = ht[hbase + hfo[k]]; }
+#pragma unroll
+                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af[k], bf[k], acc[k]);
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * PSTRIDE;
+    if (do_bias && tid < CH) out[NG * U * 256 + tid] = bsum;
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        if (k >= nu) continue;
+        const int u = wave + 4 * k;
+        // accumulator element e of lane (i, g): row m = 4g + e (input channel g0 + m), column n = i
+        float* o = out + ((size_t)gchunk * U + u) * 256;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(4 * g + e) * 16 + i] = acc[k][e];
+    }
+}
+
+struct MsGradPtrs {
+    float* dw[4];
+    float* db[4];
+};
+
+// fixed-order sum over the S partial slabs, then scatter: slab index -> (branch, out channel, in channel, tap) of the four
+// PyTorch-layout gradients  dw1 (C4, CH, 1, 1), dw2..4 (C4, CH, 3, 3)  and  db1..4 (C4)
+template <int CH>
+__global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __restrict__ partial, MsGradPtrs out, int S) {
+    constexpr int NFH = CH / 16, C4 = CH / 4, U = NFH + 24, NG = CH / 16, NACC = NG * U * 256, PSTRIDE = NACC + CH;
+    __shared__ float sh[16][17];
+    const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + e;
+    float sum = 0.f;
+    if (idx < PSTRIDE)
+        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    sh[row][e] = sum;
+    __syncthreads();
+    if (row != 0 || idx >= PSTRIDE) return;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += sh[k][e];
+    if (idx >= NACC) {  // bias gradient of output channel co
+        const int co = idx - NACC;
+        out.db[co / C4][co % C4] = r;
+        return;
+    }
+    const int n = idx & 15, m = (idx >> 4) & 15, u = (idx >> 8) % U, gch = idx / (U * 256);
+    const int ci = 16 * gch + m;
+    if (u < NFH) {  // centre tap, fragment u
+        const int co = 16 * u + n, j = co / C4, cj = co % C4;
+        if (j == 0) out.dw[0][cj * CH + ci] = r;
+        else out.dw[j][(cj * CH + ci) * 9 + 4] = r;
+    } else {
+        const int rr = (u - NFH) >> 3, i8 = (u - NFH) & 7, t9 = i8 < 4 ? i8 : i8 + 1, j = rr + 1;
+        const int co = 16 * ((j * C4) / 16) + n;
+        if (co >= j * C4 && co < (j + 1) * C4) out.dw[j][((co - j * C4) * CH + ci) * 9 + t9] = r;
+    }
+}
+
+template <int CH>
+static size_t ms_wgrad_plan(int N, int H, int W, int& S, int& tiles_x, int& tiles_y, int& ntiles) {
+    constexpr int NFH = CH / 16, U = NFH + 24, NG = CH / 16, PSTRIDE = NG * U * 256 + CH;
+    tiles_x = cdiv(W, 16);
+    tiles_y = cdiv(H, MS_TH);
+    ntiles = N * tiles_x * tiles_y;
+    S = 768 / NG;
+    if (S > ntiles) S = ntiles;
+    if (S < 1) S = 1;
+    return (size_t)S * PSTRIDE * sizeof(float);
+}
+
+template <int CH>
+static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& out, int N, int H, int W, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    constexpr int NFH = CH / 16, U = NFH + 24, NG = CH / 16, PSTRIDE = NG * U * 256 + CH;
+    int S, tiles_x, tiles_y, ntiles;
+    const size_t need = ms_wgrad_plan<CH>(N, H, W, S, tiles_x, tiles_y, ntiles);
+    if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_wgrad: workspace too small");
+    const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP + MS_TH * 16 * (CH + 4)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ms_kernel<CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad_ms)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_ms_kernel<CH>), dim3(S, NG, 1), dim3(256), lds, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
+    MSTG_CHECK_LAUNCH("wgrad_ms_kernel");
+    hipLaunchKernelGGL((wgrad_ms_reduce_kernel<CH>), dim3(cdiv(PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S);
+    MSTG_CHECK_LAUNCH("wgrad_ms_reduce_kernel");
+    return MSTG_OK;
+}
+
+}  // namespace mstg
+
+using namespace mstg;
+
+extern "C" int mstg_msblock_fused_supported(int CH) { return CH == 16 || CH == 32 || CH == 64; }
+
+extern "C" size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH) {
+    int S, tx, ty, nt;
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    if (CH == 16) return ms_wgrad_plan<16>(N, H, W, S, tx, ty, nt);
+    if (CH == 32) return ms_wgrad_plan<32>(N, H, W, S, tx, ty, nt);
+    if (CH == 64) return ms_wgrad_plan<64>(N, H, W, S, tx, ty, nt);
+    return 0;
+}
+
+extern "C" int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
+                                  float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!x || !dy || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || !dw4 || !db4) return fail_arg(MSTG_E_BADARG, "msblock_wgrad: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "msblock_wgrad: bad shape");
+    if ((uint64_t)H * W * CH >= (1ull << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "msblock_wgrad: one image must stay below 2^30 elements");
+    MsGradPtrs out{{dw1, dw2, dw3, dw4}, {db1, db2, db3, db4}};
+    hipStream_t st = (hipStream_t)stream;
+    if (CH == 16) return launch_ms_wgrad<16>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 32) return launch_ms_wgrad<32>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 64) return launch_ms_wgrad<64>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
+    return fail_arg(MSTG_E_UNSUPPORTED, "msblock_wgrad: fused path exists for 16, 32 and 64 channels");
+}

@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -233,16 +235,25 @@ class MSBranchesFn(torch.autograd.Function):
         x, *ws = ctx.saved_tensors
         dy = _req(dy, "multi-scale grad_output")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        lib = _lib.load()
+        fused = os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch
         grads = []
         for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
             d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4, accumulate=int(j > 0))
             if dx is not None:
                 conv_dgrad_raw(d, dy, ws[j], dx)
             dw = torch.empty_like(ws[j])
-            d.accumulate = 0
             db = torch.empty(c4, dtype=torch.float32, device=dy.device)
-            conv_wgrad_raw(d, x, dy, dw, db)
+            if not fused:
+                d.accumulate = 0
+                conv_wgrad_raw(d, x, dy, dw, db)
             grads += [dw, db]
+        if fused:  # all eight parameter gradients in one pass over x and dy
+            wsb = _ws(lib.mstg_msblock_wgrad_workspace_bytes(N, H, W, ch), x.device)
+            _timed(f"wgrad_ms_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
+                   lambda: _lib.check(lib.mstg_msblock_wgrad(_p(x), _p(dy), *[_p(t) for t in grads], N, H, W, ch, _p(wsb),
+                                                             wsb.numel() * 4, _stream()), "mstg_msblock_wgrad"),
+                   f"ms-wgrad N{N} {H}x{W} ch{ch}")
         return (dx, *grads)
 
 

@@ -164,10 +164,12 @@ def test_spectral_norm_fused_vs_torch(shape):
         report(f"spectral_norm {shape} it{it} dweight_orig", rel_l2(dw, dw_ref), 1e-4)
 
 
-def test_conv_channel_slices_and_accumulate():
-    """The multi-scale block's four branches: output into channel slices of one buffer, input gradients accumulated."""
+@pytest.mark.parametrize("N,H,W,ch", [(2, 16, 24, 16), (2, 21, 37, 16), (1, 32, 32, 32), (2, 9, 20, 64), (3, 40, 56, 16), (1, 16, 16, 8),
+                                      (1, 8, 8, 128)])
+def test_conv_channel_slices_and_accumulate(N, H, W, ch):
+    """The multi-scale block's four branches: output into channel slices of one buffer, input gradients accumulated, and
+    (16 / 32 / 64 channels) the eight parameter gradients from the fused one-pass kernel; other widths per branch."""
     from mstg_hip import ops
-    N, H, W, ch = 2, 16, 24, 16
     x = rnd((N, ch, H, W), 5)
     ws = [rnd((ch // 4, ch, k, k), 6 + j, 0.2) for j, k in enumerate((1, 3, 3, 3))]
     bs = [rnd((ch // 4,), 10 + j, 0.2) for j in range(4)]
