@@ -149,6 +149,11 @@ int mstg_adam_step_flat(float* p, const float* g, float* m, float* v, size_t n, 
  * concatenated).  dw1 (CH/4,CH,1,1), dw2..4 (CH/4,CH,3,3), db1..4 (CH/4), PyTorch layouts.  CH in {16, 32, 64}
  * (mstg_msblock_fused_supported); other widths use mstg_conv2d_wgrad per branch. */
 int mstg_msblock_fused_supported(int CH);
+/* forward of the four branches: x (N,H,W,CH) -> y (N,H,W,CH) = [1x1 | 3x3 d1 | 3x3 d2 | 3x3 d4] + biases, one staging of x */
+size_t mstg_msblock_fwd_workspace_bytes(int CH);
+int mstg_msblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                     const float* b3, const float* w4, const float* b4, float* y, int N, int H, int W, int CH, void* workspace,
+                     size_t workspace_bytes, void* stream);
 size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH);
 int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                        float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);

@@ -91,6 +91,123 @@ __global__ __launch_bounds__(256) void wgrad_ms_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Forward of the four branches in one launch.  GEMM view per 8x16 tile: M = output channels (filter rows, 16 per fragment),
+// N = 16 pixels, K = (tap, input channel).  The input patch (halo 4, 16 channels per chunk) is staged ONCE for all 25 taps; a
+// "unit" = (tap, output fragment) exactly as in the weight gradient: the centre tap feeds every fragment, a ring tap only the
+// fragment its branch lives in.  The unit loop is fully unrolled (all patch offsets are immediates) and the filter fragments
+// come straight from the packed filter in L2 (1 KiB per unit and chunk, lane-linear), so LDS holds only the patch and five
+// workgroups fit on a CU.  The output is written as whole pixels (all CH channels), not as four strided channel slices.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CH>
+struct MsUnits {
+    static constexpr int NFW = CH / 16, C4 = CH / 4, U = NFW + 24;
+    // unit u -> patch offset of its tap and the output fragment it feeds
+    __host__ __device__ static constexpr int ring(int u) { return (u - NFW) >> 3; }
+    __host__ __device__ static constexpr int t9(int u) { return ((u - NFW) & 7) < 4 ? ((u - NFW) & 7) : ((u - NFW) & 7) + 1; }
+    __host__ __device__ static constexpr int oy(int u) { return u < NFW ? 0 : (t9(u) / 3 - 1) * (1 << ring(u)); }
+    __host__ __device__ static constexpr int ox(int u) { return u < NFW ? 0 : (t9(u) % 3 - 1) * (1 << ring(u)); }
+    __host__ __device__ static constexpr int frag(int u) { return u < NFW ? u : ((ring(u) + 1) * C4) / 16; }
+};
+
+struct MsParamPtrs {
+    const float* w[4];
+    const float* b[4];
+};
+
+// packed forward filter: wp[((chunk * U + u) * 64 + lane) * 4 + j] = A[row i = lane & 15][channel 16*chunk + 4*(lane >> 4) + j]
+// of unit u (zero where the row's output channel does not belong to the unit's branch); then CH concatenated biases.
+template <int CH>
+__global__ void ms_pack_fwd_kernel(MsParamPtrs prm, float* __restrict__ wp) {
+    typedef MsUnits<CH> G;
+    constexpr int NCH = CH / 16, TOTAL = NCH * G::U * 256;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < TOTAL + CH; idx += gridDim.x * blockDim.x) {
+        if (idx >= TOTAL) {
+            const int co = idx - TOTAL;
+            wp[idx] = prm.b[co / G::C4][co % G::C4];
+            continue;
+        }
+        const int j = idx & 3, lane = (idx >> 2) & 63, u = (idx >> 8) % G::U, chunk = idx / (G::U * 256);
+        const int i = lane & 15, g = lane >> 4, ci = 16 * chunk + 4 * g + j;
+        float v = 0.f;
+        if (u < G::NFW) {  // centre tap of every branch
+            const int co = 16 * u + i, br = co / G::C4, cj = co % G::C4;
+            v = br == 0 ? prm.w[0][cj * CH + ci] : prm.w[br][(cj * CH + ci) * 9 + 4];
+        } else {
+            const int r = (u - G::NFW) >> 3, i8 = (u - G::NFW) & 7, t9 = i8 < 4 ? i8 : i8 + 1, br = r + 1;
+            const int co = 16 * ((br * G::C4) / 16) + i;
+            if (co >= br * G::C4 && co < (br + 1) * G::C4) v = prm.w[br][((co - br * G::C4) * CH + ci) * 9 + t9];
+        }
+        wp[idx] = v;
+    }
+}
+
+template <int CH, int UB, int UE>
+struct MsFwdUnitLoop {
+    template <typename ACC>
+    static __device__ __forceinline__ void run(ACC& acc, const float* __restrict__ wpc, const float* __restrict__ patch, int pbase, int lane) {
+        typedef MsUnits<CH> G;
+        constexpr int u = UB;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wpc + u * 256 + lane * 4);
+        constexpr int off = (G::oy(u) * MS_PW + G::ox(u)) * MS_CKP;
+        f32x4 b[2];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) b[pf] = *reinterpret_cast<const f32x4*>(&patch[pbase + pf * MS_PW * MS_CKP + off]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) acc[G::frag(u)][pf] = mfma16(a[j], b[pf][j], acc[G::frag(u)][pf]);
+        MsFwdUnitLoop<CH, UB + 1, UE>::run(acc, wpc, patch, pbase, lane);
+    }
+};
+template <int CH, int UE>
+struct MsFwdUnitLoop<CH, UE, UE> {
+    template <typename ACC>
+    static __device__ __forceinline__ void run(ACC&, const float*, const float*, int, int) {}
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void ms_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                     int N, int H, int W, int tiles_x, int tiles_y) {
+    typedef MsUnits<CH> G;
+    constexpr int NFW = G::NFW, NCH = CH / 16, PF = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;  // [PH][PW][CKP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const size_t plane = (size_t)H * W;
+    const unsigned m_pw = magic_u32(MS_PW);
+    // bias of this lane's output channels (in flight while the patch is staged)
+    f32x4 bq[NFW];
+#pragma unroll
+    for (int wf = 0; wf < NFW; ++wf) bq[wf] = *reinterpret_cast<const f32x4*>(wp + NCH * G::U * 256 + 16 * wf + 4 * g);
+
+    f32x4 acc[NFW][PF];
+#pragma unroll
+    for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B fragment of (pixel row PF*wave + pf, column i) at tap (0,0): patch row +4, column +4
+    const int pbase = ((PF * wave + 4) * MS_PW + i + 4) * MS_CKP + 4 * g;
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        if (chunk) __syncthreads();
+        stage_window(x + (size_t)n * plane * CH + 16 * chunk, patch, MS_PH, MS_PW, 4, m_pw, 0x40000000u, ty0 * MS_TH - 4, tx0 * 16 - 4, H, W,
+                     CH, 4, MS_CKP, tid);
+        __syncthreads();
+        MsFwdUnitLoop<CH, 0, G::U>::run(acc, wp + (size_t)chunk * G::U * 256, patch, pbase, lane);
+    }
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int gy = ty0 * MS_TH + PF * wave + pf, gx = tx0 * 16 + i;
+        if (gy < H && gx < W) {
+            float* p = y + (((size_t)n * H + gy) * W + gx) * CH + 4 * g;
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) *reinterpret_cast<f32x4*>(p + 16 * wf) = acc[wf][pf] + bq[wf];
+        }
+    }
+}
+
 struct MsGradPtrs {
     float* dw[4];
     float* db[4];
@@ -165,11 +282,47 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
     return MSTG_OK;
 }
 
+template <int CH>
+static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
+    typedef MsUnits<CH> G;
+    constexpr int NCH = CH / 16;
+    const size_t need = (size_t)(NCH * G::U * 256 + CH) * sizeof(float);
+    if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_fwd: workspace too small");
+    float* wp = (float*)ws;
+    hipLaunchKernelGGL((ms_pack_fwd_kernel<CH>), dim3(cdiv(NCH * G::U * 256 + CH, 256)), dim3(256), 0, st, prm, wp);
+    MSTG_CHECK_LAUNCH("ms_pack_fwd_kernel");
+    const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
+    const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
+    hipLaunchKernelGGL((ms_fwd_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, (const float*)wp, y, N, H, W, tiles_x,
+                       tiles_y);
+    MSTG_CHECK_LAUNCH("ms_fwd_kernel");
+    return MSTG_OK;
+}
+
 }  // namespace mstg
 
 using namespace mstg;
 
 extern "C" int mstg_msblock_fused_supported(int CH) { return CH == 16 || CH == 32 || CH == 64; }
+
+extern "C" size_t mstg_msblock_fwd_workspace_bytes(int CH) {
+    if (!mstg_msblock_fused_supported(CH)) return 0;
+    return (size_t)((CH / 16) * (CH / 16 + 24) * 256 + CH) * sizeof(float);
+}
+
+extern "C" int mstg_msblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                const float* b3, const float* w4, const float* b4, float* y, int N, int H, int W, int CH, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    if (!x || !y || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !w4 || !b4) return fail_arg(MSTG_E_BADARG, "msblock_fwd: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "msblock_fwd: bad shape");
+    if ((uint64_t)H * W * CH >= (1ull << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "msblock_fwd: one image must stay below 2^30 elements");
+    MsParamPtrs prm{{w1, w2, w3, w4}, {b1, b2, b3, b4}};
+    hipStream_t st = (hipStream_t)stream;
+    if (CH == 16) return launch_ms_fwd<16>(x, prm, y, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 32) return launch_ms_fwd<32>(x, prm, y, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 64) return launch_ms_fwd<64>(x, prm, y, N, H, W, workspace, workspace_bytes, st);
+    return fail_arg(MSTG_E_UNSUPPORTED, "msblock_fwd: fused path exists for 16, 32 and 64 channels");
+}
 
 extern "C" size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH) {
     int S, tx, ty, nt;

@@ -222,9 +222,19 @@ class MSBranchesFn(torch.autograd.Function):
         N, H, W, ch = x.shape
         c4 = ws[0].shape[0]
         y = torch.empty((N, H, W, 4 * c4), dtype=torch.float32, device=x.device)
-        for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
-            d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4)
-            conv_fwd_raw(d, x, ws[j], bs[j], y)
+        lib = _lib.load()
+        if os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch:
+            wsb = _ws(lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
+            wb_ptrs = []
+            for j in range(4):
+                wb_ptrs += [_p(ws[j]), _p(bs[j])]
+            _timed(f"ms_fwd_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
+                   lambda: _lib.check(lib.mstg_msblock_fwd(_p(x), *wb_ptrs, _p(y), N, H, W, ch, _p(wsb), wsb.numel() * 4, _stream()),
+                                      "mstg_msblock_fwd"), f"ms-fwd N{N} {H}x{W} ch{ch}")
+        else:
+            for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
+                d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4)
+                conv_fwd_raw(d, x, ws[j], bs[j], y)
         ctx.dims = (N, H, W, ch, c4)
         ctx.save_for_backward(x, *ws)
         return y
