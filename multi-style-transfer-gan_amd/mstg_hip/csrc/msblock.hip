@@ -208,6 +208,143 @@ __global__ __launch_bounds__(256) void ms_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input gradient of the four branches in one launch: dx = sum over branches of conv_transpose(dy_branch, W_branch).
+// GEMM view per 8x16 tile: M = input channels (16 per fragment), N = 16 pixels, K = (tap, output channel of that tap's branch).
+// The reduction runs over the channels of dy, and a tap only touches the channel slice of its own branch, so K is walked in
+// groups of 4 consecutive dy channels (one MFMA each): the centre tap uses every group, a ring tap the groups of its branch.
+// A "slot" = (tap, channel group); slots are compile-time tables per 16-channel chunk of dy, the filter comes from L2 packed
+// four slots per 16-byte load, and dx is written once as whole pixels (the per-branch path reads and rewrites dx three times).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CH, int C>
+struct MsDgChunk {
+    static constexpr int C4 = CH / 4;
+    static constexpr int FG = (C4 / 4 - 4 * C) < 0 ? 0 : ((C4 / 4 - 4 * C) > 4 ? 4 : (C4 / 4 - 4 * C));  // groups of branch 0 in this chunk
+    static constexpr int NRG = 4 - FG, NS = 4 + 8 * NRG, NQ = (NS + 3) / 4;
+    __host__ __device__ static constexpr int grp(int s) { return s < 4 ? s : FG + (s - 4) % (NRG > 0 ? NRG : 1); }
+    __host__ __device__ static constexpr int br(int s) { return (16 * C + 4 * grp(s)) / C4; }
+    __host__ __device__ static constexpr int t9(int s) { return ((s - 4) / (NRG > 0 ? NRG : 1)) < 4 ? (s - 4) / (NRG > 0 ? NRG : 1) : (s - 4) / (NRG > 0 ? NRG : 1) + 1; }
+    __host__ __device__ static constexpr int dil(int s) { return 1 << (br(s) - 1); }
+    // dx[p] += W[ky][kx]^T dy[p - (ky-1) d, p - (kx-1) d]
+    __host__ __device__ static constexpr int oy(int s) { return s < 4 ? 0 : -(t9(s) / 3 - 1) * dil(s); }
+    __host__ __device__ static constexpr int ox(int s) { return s < 4 ? 0 : -(t9(s) % 3 - 1) * dil(s); }
+};
+template <int CH>
+__host__ __device__ constexpr int ms_dg_quads_before(int c) {
+    return (c > 0 ? MsDgChunk<CH, 0>::NQ : 0) + (c > 1 ? MsDgChunk<CH, 1>::NQ : 0) + (c > 2 ? MsDgChunk<CH, 2>::NQ : 0) +
+           (c > 3 ? MsDgChunk<CH, 3>::NQ : 0);
+}
+
+// wp[((quads_before(c) * NFW + wf * NQ(c) + quad) * 64 + lane) * 4 + e] = W_br[cj][ci = 16 wf + (lane & 15)][tap] of slot 4 quad + e,
+// cj = (16 c + 4 grp + (lane >> 4)) - br * C4
+template <int CH, int C>
+__device__ void ms_pack_dgrad_chunk(const MsParamPtrs& prm, float* __restrict__ wp, int tid, int nthreads) {
+    typedef MsDgChunk<CH, C> K;
+    constexpr int NFW = CH / 16, C4 = CH / 4;
+    float* base = wp + (size_t)ms_dg_quads_before<CH>(C) * NFW * 256;
+    for (int idx = tid; idx < NFW * K::NQ * 256; idx += nthreads) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, quad = (idx >> 8) % K::NQ, wf = idx / (K::NQ * 256);
+        const int s = 4 * quad + e, i = lane & 15, g = lane >> 4;
+        float v = 0.f;
+        if (s < K::NS) {
+            const int br = K::br(s), cj = 16 * C + 4 * K::grp(s) + g - br * C4, ci = 16 * wf + i;
+            if (s < 4) v = br == 0 ? prm.w[0][cj * CH + ci] : prm.w[br][(cj * CH + ci) * 9 + 4];
+            else v = prm.w[br][(cj * CH + ci) * 9 + K::t9(s)];
+        }
+        base[idx] = v;
+    }
+}
+template <int CH>
+__global__ void ms_pack_dgrad_kernel(MsParamPtrs prm, float* __restrict__ wp) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    ms_pack_dgrad_chunk<CH, 0>(prm, wp, tid, nt);
+    if (CH >= 32) ms_pack_dgrad_chunk<CH, (CH >= 32 ? 1 : 0)>(prm, wp, tid, nt);
+    if (CH >= 64) {
+        ms_pack_dgrad_chunk<CH, (CH >= 64 ? 2 : 0)>(prm, wp, tid, nt);
+        ms_pack_dgrad_chunk<CH, (CH >= 64 ? 3 : 0)>(prm, wp, tid, nt);
+    }
+}
+
+template <int CH, int C, int QB, int QE>
+struct MsDgQuadLoop {
+    template <typename ACC>
+    static __device__ __forceinline__ void run(ACC& acc, const float* __restrict__ wpc, const float* __restrict__ patch, int pbase, int lane) {
+        typedef MsDgChunk<CH, C> K;
+        constexpr int NFW = CH / 16, Q = QB;
+        f32x4 a[NFW];
+#pragma unroll
+        for (int wf = 0; wf < NFW; ++wf) a[wf] = *reinterpret_cast<const f32x4*>(wpc + ((wf * K::NQ + Q) * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            constexpr int s0 = 4 * Q;
+            const int s = s0 + e;
+            if (s < K::NS) {
+                const int off = (K::oy(s) * MS_PW + K::ox(s)) * MS_CKP + 4 * K::grp(s);
+                float b[2];
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) b[pf] = patch[pbase + pf * MS_PW * MS_CKP + off];
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+                    for (int pf = 0; pf < 2; ++pf) acc[wf][pf] = mfma16(a[wf][e], b[pf], acc[wf][pf]);
+            }
+        }
+        MsDgQuadLoop<CH, C, QB + 1, QE>::run(acc, wpc, patch, pbase, lane);
+    }
+};
+template <int CH, int C, int QE>
+struct MsDgQuadLoop<CH, C, QE, QE> {
+    template <typename ACC>
+    static __device__ __forceinline__ void run(ACC&, const float*, const float*, int, int) {}
+};
+
+template <int CH, int C, typename ACC>
+__device__ __forceinline__ void ms_dgrad_chunk(ACC& acc, const float* __restrict__ dy_img, const float* __restrict__ wp, float* patch,
+                                               int ty0, int tx0, int H, int W, unsigned m_pw, int pbase, int tid, int lane) {
+    typedef MsDgChunk<CH, C> K;
+    constexpr int NFW = CH / 16;
+    if (C) __syncthreads();
+    stage_window(dy_img + 16 * C, patch, MS_PH, MS_PW, 4, m_pw, 0x40000000u, ty0 * MS_TH - 4, tx0 * 16 - 4, H, W, CH, 4, MS_CKP, tid);
+    __syncthreads();
+    MsDgQuadLoop<CH, C, 0, K::NQ>::run(acc, wp + (size_t)ms_dg_quads_before<CH>(C) * NFW * 256, patch, pbase, lane);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void ms_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wp, float* __restrict__ dx,
+                                                       int N, int H, int W, int tiles_x, int tiles_y) {
+    constexpr int NFW = CH / 16, PF = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const size_t plane = (size_t)H * W;
+    const unsigned m_pw = magic_u32(MS_PW);
+    f32x4 acc[NFW][PF];
+#pragma unroll
+    for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+        for (int pf = 0; pf < PF; ++pf) acc[wf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // B value of (pixel row PF*wave + pf, column i), k-slot g, at tap (0,0) and channel group 0
+    const int pbase = ((PF * wave + 4) * MS_PW + i + 4) * MS_CKP + g;
+    const float* dy_img = dy + (size_t)n * plane * CH;
+    ms_dgrad_chunk<CH, 0>(acc, dy_img, wp, patch, ty0, tx0, H, W, m_pw, pbase, tid, lane);
+    if (CH >= 32) ms_dgrad_chunk<CH, (CH >= 32 ? 1 : 0)>(acc, dy_img, wp, patch, ty0, tx0, H, W, m_pw, pbase, tid, lane);
+    if (CH >= 64) {
+        ms_dgrad_chunk<CH, (CH >= 64 ? 2 : 0)>(acc, dy_img, wp, patch, ty0, tx0, H, W, m_pw, pbase, tid, lane);
+        ms_dgrad_chunk<CH, (CH >= 64 ? 3 : 0)>(acc, dy_img, wp, patch, ty0, tx0, H, W, m_pw, pbase, tid, lane);
+    }
+#pragma unroll
+    for (int pf = 0; pf < PF; ++pf) {
+        const int gy = ty0 * MS_TH + PF * wave + pf, gx = tx0 * 16 + i;
+        if (gy < H && gx < W) {
+            float* p = dx + (((size_t)n * H + gy) * W + gx) * CH + 4 * g;
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) *reinterpret_cast<f32x4*>(p + 16 * wf) = acc[wf][pf];
+        }
+    }
+}
+
 struct MsGradPtrs {
     float* dw[4];
     float* db[4];
@@ -299,9 +436,50 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
     return MSTG_OK;
 }
 
+template <int CH>
+static size_t ms_dgrad_ws_floats() {
+    return (size_t)ms_dg_quads_before<CH>(CH / 16) * (CH / 16) * 256;
+}
+
+template <int CH>
+static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, float* dx, int N, int H, int W, void* ws, size_t ws_bytes,
+                           hipStream_t st) {
+    const size_t need = ms_dgrad_ws_floats<CH>() * sizeof(float);
+    if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_dgrad: workspace too small");
+    float* wp = (float*)ws;
+    hipLaunchKernelGGL((ms_pack_dgrad_kernel<CH>), dim3(cdiv((int)ms_dgrad_ws_floats<CH>(), 1024)), dim3(256), 0, st, prm, wp);
+    MSTG_CHECK_LAUNCH("ms_pack_dgrad_kernel");
+    const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
+    const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
+    hipLaunchKernelGGL((ms_dgrad_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, dy, (const float*)wp, dx, N, H, W, tiles_x,
+                       tiles_y);
+    MSTG_CHECK_LAUNCH("ms_dgrad_kernel");
+    return MSTG_OK;
+}
+
 }  // namespace mstg
 
 using namespace mstg;
+
+extern "C" size_t mstg_msblock_dgrad_workspace_bytes(int CH) {
+    if (CH == 16) return ms_dgrad_ws_floats<16>() * sizeof(float);
+    if (CH == 32) return ms_dgrad_ws_floats<32>() * sizeof(float);
+    if (CH == 64) return ms_dgrad_ws_floats<64>() * sizeof(float);
+    return 0;
+}
+
+extern "C" int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, float* dx, int N,
+                                  int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !dx || !w1 || !w2 || !w3 || !w4) return fail_arg(MSTG_E_BADARG, "msblock_dgrad: null pointer");
+    if (N <= 0 || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "msblock_dgrad: bad shape");
+    if ((uint64_t)H * W * CH >= (1ull << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "msblock_dgrad: one image must stay below 2^30 elements");
+    MsParamPtrs prm{{w1, w2, w3, w4}, {nullptr, nullptr, nullptr, nullptr}};
+    hipStream_t st = (hipStream_t)stream;
+    if (CH == 16) return launch_ms_dgrad<16>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 32) return launch_ms_dgrad<32>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 64) return launch_ms_dgrad<64>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
+    return fail_arg(MSTG_E_UNSUPPORTED, "msblock_dgrad: fused path exists for 16, 32 and 64 channels");
+}
 
 extern "C" int mstg_msblock_fused_supported(int CH) { return CH == 16 || CH == 32 || CH == 64; }
 

@@ -248,9 +248,14 @@ class MSBranchesFn(torch.autograd.Function):
         lib = _lib.load()
         fused = os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch
         grads = []
+        if fused and dx is not None:  # dx of all four branches in one pass over dy, written once
+            wsd = _ws(lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
+            _timed(f"ms_dgrad_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
+                   lambda: _lib.check(lib.mstg_msblock_dgrad(_p(dy), *[_p(t) for t in ws], _p(dx), N, H, W, ch, _p(wsd), wsd.numel() * 4,
+                                                             _stream()), "mstg_msblock_dgrad"), f"ms-dgrad N{N} {H}x{W} ch{ch}")
         for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
             d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4, accumulate=int(j > 0))
-            if dx is not None:
+            if dx is not None and not fused:
                 conv_dgrad_raw(d, dy, ws[j], dx)
             dw = torch.empty_like(ws[j])
             db = torch.empty(c4, dtype=torch.float32, device=dy.device)
