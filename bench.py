@@ -141,7 +141,7 @@ def main():
         table = ops.KernelTimer.summary()
         total_ms = sum(r["ms"] for r in table.values())
         if args.kernel_table:
-            for sym, r in sorted(ops.KernelTimer.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:60]:
+            for sym, r in sorted(ops.KernelTimer.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:200]:
                 print(f"[kernels] {sym:72s} launches {r['launches']:5d}  {r['ms']:9.3f} ms  {100 * r['ms'] / total_ms:5.1f}%  "
                       f"{r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:8.2f} TFLOP/s  {r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0:9.1f} GB/s",
                       file=sys.stderr)

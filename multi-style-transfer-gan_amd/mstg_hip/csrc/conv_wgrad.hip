@@ -366,6 +366,148 @@ __global__ __launch_bounds__(256) void wgrad_ts_kernel(const WGradArgs a, const 
     }
 }
 
+// =====================================================================================================================
+// 1x1 convolutions: the weight gradient is a plain GEMM  dW[ci][co] = sum_p x[p][ci] dy[p][co]  over all P = N*H*W pixels,
+// with no spatial structure at all.  The generic kernel above still tiles it in 2-D and gives every (16 input channels,
+// 32 output channels) pair its own workgroup column, so x is re-read Ch/32 times and dy Cg/16 times.  Here a workgroup owns
+// a run of pixels and ALL channels: it stages [32 pixels][Cg] and [32 pixels][Ch] once (rows are contiguous in NHWC), the
+// four waves split the output-channel fragments, and each wave keeps MF x NW accumulators (MF = Cg/16 fragments of input
+// channels, NW = its share of the Ch/16 output fragments).  x and dy are read exactly once.
+// =====================================================================================================================
+// pixels per staged tile: about eight 16-byte loads per thread (32 pixels at 64 + 192 channels, 256 at 16 + 16)
+static int wgrad_1x1_tile(int Cg, int Ch) {
+    int p1 = (2048 / ((Cg + Ch) >> 2)) & ~3;
+    return p1 < 32 ? 32 : (p1 > 256 ? 256 : p1);
+}
+
+template <int MF, int NW>
+__global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                        long P, int Cg, int g_ctot, int g_coff, int Ch, int h_ctot, int h_coff,
+                                                        int with_bias, int P1) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lda = 16 * MF + 4, NF = (Ch + 15) / 16, ldb = 16 * NF + 4;
+    float* As = smem;             // [P1][lda]
+    float* Bs = smem + P1 * lda;  // [P1][ldb]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    f32x4 acc[MF][NW];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+        for (int k = 0; k < NW; ++k) acc[mf][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // fewer than four output fragments: the spare waves take every KS-th pixel group of the same fragments instead
+    const int KS = NF >= 3 ? 1 : (NF == 2 ? 2 : 4), wslot = wave % (4 / KS), kpart = wave / (4 / KS);
+    const int qa = Cg >> 2, qb = Ch >> 2;          // channel quads per pixel
+    const int ea = P1 * qa, eb = P1 * qb;          // float4 elements of the two tiles
+    const unsigned m_qa = magic_u32(qa), m_qb = magic_u32(qb);
+    float bsum = 0.f;
+    const long ntiles = (P + P1 - 1) / P1;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long p0 = tile * P1;
+        __syncthreads();
+        // ---- stage both tiles: up to 8 + 8 independent 16-byte loads per thread, rows beyond P zero ---------------------------
+        for (int e0 = 0; e0 < ea + eb; e0 += 2048) {
+            f32x4 v[8];
+            int dst[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 256 * k + tid;
+                const bool isa = e < ea;
+                const int eb_ = e - ea;
+                const int pr = isa ? (qa == 1 ? e : (int)__umulhi((unsigned)e, m_qa)) : (qb == 1 ? eb_ : (int)__umulhi((unsigned)(eb_ < 0 ? 0 : eb_), m_qb));
+                const int q = isa ? e - pr * qa : eb_ - pr * qb;
+                const bool ok = e < ea + eb && p0 + pr < P;
+                const float* src = isa ? x + (size_t)(p0 + (ok ? pr : 0)) * g_ctot + g_coff + 4 * q
+                                       : dy + (size_t)(p0 + (ok ? pr : 0)) * h_ctot + h_coff + 4 * (ok ? q : 0);
+                v[k] = *reinterpret_cast<const f32x4*>(e < ea + eb ? src : x);
+                if (!ok) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[k] = e >= ea + eb ? -1 : (isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (dst[k] >= 0) *reinterpret_cast<f32x4*>(&smem[dst[k]]) = v[k];
+        }
+        __syncthreads();
+        if (with_bias && tid < Ch) {
+#pragma unroll 8
+            for (int p = 0; p < P1; ++p) bsum += Bs[p * ldb + tid];
+        }
+        // ---- MFMA: K = the tile's 32 pixels, 4 per step ---------------------------------------------------------------------------
+#pragma unroll 2
+        for (int k0 = 4 * kpart; k0 < P1; k0 += 4 * KS) {
+            float af[MF], bf[NW];
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) af[mf] = As[(k0 + g) * lda + 16 * mf + i];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int nf = min(wslot + 4 * k, NF - 1);
+                bf[k] = Bs[(k0 + g) * ldb + 16 * nf + i];
+            }
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+                for (int k = 0; k < NW; ++k) acc[mf][k] = mfma16(af[mf], bf[k], acc[mf][k]);
+        }
+    }
+    if (KS > 1) {  // sum the k-parts of a fragment through LDS in a fixed order (NW == 1 here)
+        __syncthreads();
+        float* red = smem;  // [wave][MF][64 lanes][4]
+        if (kpart > 0) {
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf) *reinterpret_cast<f32x4*>(&red[((wave * MF + mf) * 64 + lane) * 4]) = acc[mf][0];
+        }
+        __syncthreads();
+        if (kpart == 0) {
+            for (int kp = 1; kp < KS; ++kp) {
+                const int w2 = kp * (4 / KS) + wslot;
+#pragma unroll
+                for (int mf = 0; mf < MF; ++mf) acc[mf][0] += *reinterpret_cast<const f32x4*>(&red[((w2 * MF + mf) * 64 + lane) * 4]);
+            }
+        }
+    }
+    // partial slab [Cg][Ch] (+ [Ch] bias tail), the layout wgrad_reduce_kernel expects for T = 1
+    const size_t pstride = (size_t)Cg * Ch + (with_bias ? Ch : 0);
+    float* out = partial + (size_t)blockIdx.x * pstride;
+    if (with_bias && tid < Ch) out[(size_t)Cg * Ch + tid] = bsum;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int nf = wslot + 4 * k;
+        if (nf >= NF || kpart != 0) continue;
+        const int hch = 16 * nf + i;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gch = 16 * mf + 4 * g + e;
+                if (gch < Cg && hch < Ch) out[(size_t)gch * Ch + hch] = acc[mf][k][e];
+            }
+    }
+}
+
+template <int MF, int NW>
+static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st) {
+    const int NF = cdiv(a.Ch, 16), P1 = wgrad_1x1_tile(a.Cg, a.Ch);
+    const size_t lds = (size_t)P1 * ((16 * MF + 4) + (16 * NF + 4)) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_1x1_kernel<MF, NW>), dim3(S), dim3(256), lds, st, a.g, a.h, a.partial, P, a.Cg, a.g_ctot, a.g_coff, a.Ch,
+                       a.h_ctot, a.h_coff, a.with_bias, P1);
+    MSTG_CHECK_LAUNCH("wgrad_1x1_kernel");
+    return MSTG_OK;
+}
+
+// eligible: 1x1, stride 1, both tensors NHWC with 16-byte aligned channel slices, <= 64 input and <= 192 output channels
+static bool wgrad_1x1_ok(const WGradArgs& a) {
+    const char* e = getenv("MSTG_WGRAD_1X1");
+    if (e && e[0] == '0') return false;
+    return a.T == 1 && a.stride == 1 && !a.g_nchw && !a.h_nchw && ((a.g_ctot | a.g_coff | a.Cg | a.h_ctot | a.h_coff | a.Ch) & 3) == 0 &&
+           a.Cg <= 64 && a.Ch <= 192 && a.Cg * a.Ch >= 256;
+}
+static int wgrad_1x1_splits(const WGradArgs& a) {
+    const int P1 = wgrad_1x1_tile(a.Cg, a.Ch);
+    const long P = (long)a.N * a.hH * a.hW, ntiles = (P + P1 - 1) / P1;
+    long S = 1024;
+    if (S > ntiles) S = ntiles;
+    return (int)S;
+}
+
 // dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]  (+ dbias[hch] from the tail of each split's block).
 // A workgroup owns 16 consecutive outputs; its 16 thread-rows stride over the splits and are combined through LDS in a
 // fixed order, so the result does not depend on scheduling.
@@ -537,7 +679,9 @@ extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass
     WGradArgs a{};
     if (check_desc(d) || fill_wgrad_args(d, nullptr, nullptr, a)) return "";
     const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
-    if (use_ts) {
+    if (wgrad_1x1_ok(a)) {
+        snprintf(name, sizeof(name), "wgrad_1x1_kernel<%d, %d>", cdiv(a.Cg, 16), cdiv(cdiv(a.Ch, 16), 4));
+    } else if (use_ts) {
         snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", plan_ts(a).UW);
     } else {
         const WGradPlan p = plan_wgrad(a);
@@ -552,7 +696,9 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
     const size_t w_old = plan_wgrad(a).ws_bytes;
     const size_t w_ts = a.Teff > 1 ? plan_ts(a).ws_bytes : 0;
-    return w_old > w_ts ? w_old : w_ts;
+    const size_t w_11 = wgrad_1x1_ok(a) ? (size_t)wgrad_1x1_splits(a) * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float) : 0;
+    size_t w = w_old > w_ts ? w_old : w_ts;
+    return w > w_11 ? w : w_11;
 }
 
 extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -570,7 +716,19 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     // measured on MI355X: the tap-split kernel wins where a workgroup gets 32 units (16 taps x 2 column fragments: the
     // stride-2 / transposed 4x4 layers with 17..32 grid channels); the pixel-split kernel elsewhere
     const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
-    if (use_ts && !(getenv("MSTG_WGRAD_OLD") && getenv("MSTG_WGRAD_OLD")[0] == '1')) {
+    if (wgrad_1x1_ok(a)) {
+        S = wgrad_1x1_splits(a);
+        if (workspace_bytes < (size_t)S * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float))
+            return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+        const long P = (long)a.N * a.hH * a.hW;
+        const int MF = cdiv(a.Cg, 16), NW = cdiv(cdiv(a.Ch, 16), 4);
+        int rc = MSTG_E_UNSUPPORTED;
+#define MSTG_W11(M_, N_) if (MF == M_ && NW == N_) rc = launch_wgrad_1x1<M_, N_>(a, P, S, st);
+        MSTG_W11(1, 1) MSTG_W11(1, 2) MSTG_W11(1, 3) MSTG_W11(2, 1) MSTG_W11(2, 2) MSTG_W11(2, 3) MSTG_W11(3, 1) MSTG_W11(3, 2) MSTG_W11(3, 3)
+        MSTG_W11(4, 1) MSTG_W11(4, 2) MSTG_W11(4, 3)
+#undef MSTG_W11
+        if (rc) return rc;
+    } else if (use_ts && !(getenv("MSTG_WGRAD_OLD") && getenv("MSTG_WGRAD_OLD")[0] == '1')) {
         const TsPlan p = plan_ts(a);
         if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
         int rc = p.UW == 4 ? launch_ts_t<4>(a, p, st) : (p.UW == 8 ? launch_ts_t<8>(a, p, st) : launch_ts_t<16>(a, p, st));
