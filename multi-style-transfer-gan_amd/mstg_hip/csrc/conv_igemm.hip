@@ -37,6 +37,7 @@ struct IGemmArgs {
     int act, accumulate;
     int dbg;
     int psz;           // stream kernel: floats reserved for the LDS patch (>= the dpack exchange tiles)
+    int wglob;         // light kernel: filter fragments straight from the packed filter in L2 (no LDS filter slice)
     int TH;            // tile height in grid rows: 8, or 16 where the light kernel gives each wave four rows
     int dpack, tapsx;  // <= 4 output channels: rows of the MFMA tile = (pixel shift delta, channel), see igemm_light_kernel
 };
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;
     float* wl = smem + ((a.PH * a.PW * CKP + 3) & ~3);
-    int* tapo = reinterpret_cast<int*>(wl + a.TG * BN * CKP);  // LDS offset of every tap inside the patch
+    int* tapo = reinterpret_cast<int*>(wl + (a.wglob ? 0 : a.TG * BN * CKP));  // LDS offset of every tap inside the patch
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -215,6 +216,44 @@ __global__ __launch_bounds__(256) void igemm_light_kernel(const IGemmArgs a, con
             }
         }
         MSTG_STAMP(1)
+        if (a.wglob) {
+            // ---- filter fragments from L2: no filter slice in LDS, no second barrier; tap t+2's fragment is in flight --------------
+            __syncthreads();
+            const float* wb = wp + ((size_t)((cls * nchunks + chunk) * a.ntaps) * CoP + co0 + i) * CK + V * g;
+            const int wts = CoP * CK;  // floats between consecutive taps
+            const int bbase0 = ((PF * wave) * s * a.PW + i * s) * CKP + V * g, bstep = s * a.PW * CKP;
+            frag_t a0[NFW], a1[NFW], a2[NFW], bf[PF], bfn[PF];
+#pragma unroll
+            for (int wf = 0; wf < NFW; ++wf) {
+                a0[wf] = *reinterpret_cast<const frag_t*>(wb + 16 * wf * CK);
+                a1[wf] = *reinterpret_cast<const frag_t*>(wb + min(1, a.ntaps - 1) * wts + 16 * wf * CK);
+            }
+            {
+                const int po = tapo[0];
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
+            }
+            for (int tl = 0; tl < a.ntaps; ++tl) {
+                const int t2 = min(tl + 2, a.ntaps - 1), t1 = min(tl + 1, a.ntaps - 1);
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) a2[wf] = *reinterpret_cast<const frag_t*>(wb + t2 * wts + 16 * wf * CK);
+                const int po = tapo[t1];
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bfn[pf] = *reinterpret_cast<const frag_t*>(&patch[bbase0 + pf * bstep + po]);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int wf = 0; wf < NFW; ++wf)
+#pragma unroll
+                        for (int pf = 0; pf < PF; ++pf)
+                            acc[wf][pf] = mfma16(frag_get<V>(a0[wf], j), frag_get<V>(bf[pf], j), acc[wf][pf]);
+#pragma unroll
+                for (int wf = 0; wf < NFW; ++wf) { a0[wf] = a1[wf]; a1[wf] = a2[wf]; }
+#pragma unroll
+                for (int pf = 0; pf < PF; ++pf) bf[pf] = bfn[pf];
+            }
+            continue;
+        }
         for (int t0 = 0; t0 < a.ntaps; t0 += a.TG) {
             __syncthreads();  // patch staged / previous tap group consumed
             MSTG_STAMP(2)
@@ -852,6 +891,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     igemm_geometry(a, TILE_H);
     p.pf = 2;
     p.stream = 0;
+    a.wglob = 0;
     p.gx = 0;
     if (a.N <= 0 || a.Gh <= 0 || a.Gw <= 0 || a.Co <= 0 || a.Cr <= 0) return fail_arg(MSTG_E_BADARG, "conv: empty tensor");
     if (a.x_nchw) {
@@ -930,7 +970,9 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
             const char* e = getenv("MSTG_PF");
             const int force = e ? atoi(e) : 0;
             const int ph16 = a.phase ? 18 : (a.dpack ? 15 + a.KH : 15 * a.stride + (a.KH - 1) * a.dil + 1);
-            const size_t lds16 = ((size_t)((ph16 * a.PW * p.CKP + 3) & ~3) + (size_t)tg * p.BN * p.CKP + 64) * sizeof(float);
+            const char* ew = getenv("MSTG_WGLOB");
+            const int wg16 = ew ? atoi(ew) : (p.V == 4 ? 1 : 0);
+            const size_t lds16 = ((size_t)((ph16 * a.PW * p.CKP + 3) & ~3) + (wg16 ? 0 : (size_t)tg * p.BN * p.CKP) + 64) * sizeof(float);
             const long blocks16 = (long)a.N * a.tiles_x * cdiv(a.Gh, 16) * (p.CoP / p.BN) * p.ncls;
             if (force == 4 || (force != 2 && lds16 <= 52 * 1024 && blocks16 >= 1024 && a.Gh >= 16)) {
                 p.pf = 4;
@@ -939,7 +981,13 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
         }
         const size_t patch_floats_l = (size_t)((a.PH * a.PW * p.CKP + 3) & ~3);
         p.TG = a.TG = tg;
-        p.lds = (patch_floats_l + (size_t)tg * p.BN * p.CKP + 64) * sizeof(float);  // + tap-offset table (<= 64 taps)
+        {
+            // filter fragments from L2 where a tap's MFMAs (V * NFW * PF of them) are long enough to cover the fetch of the tap
+            // after next: frees the LDS of the filter slice (more workgroups per CU) and its staging barrier
+            const char* e = getenv("MSTG_WGLOB");
+            a.wglob = e ? atoi(e) : (p.V == 4 ? 1 : 0);
+        }
+        p.lds = (patch_floats_l + (a.wglob ? 0 : (size_t)tg * p.BN * p.CKP) + 64) * sizeof(float);  // + tap-offset table (<= 64 taps)
         if (a.dpack && p.lds < (size_t)4 * 256 * p.pf * sizeof(float)) p.lds = (size_t)4 * 256 * p.pf * sizeof(float);
         if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv: LDS patch too large for this geometry");
     }
