@@ -67,6 +67,12 @@ __device__ __forceinline__ float row16_max(float v) {
     return v;
 }
 
+#ifdef MSTG_STAMPS
+__device__ unsigned long long g_att_stamps[64 * 8];
+#define ATT_STAMP(k) if (threadIdx.x == 0 && wcount == 2 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 64) g_att_stamps[(blockIdx.x / 31) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define ATT_STAMP(k)
+#endif
 #define WAVE_SYNC() __syncthreads() /* one-wave workgroup: orders this wave's LDS writes before its reads */
 
 // CP = C rounded up to a multiple of 16 (16, 32 or 64).  LDS tiles (floats):
@@ -95,6 +101,29 @@ __device__ __forceinline__ void load_window(const float* __restrict__ src, float
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (4 * q < C) v = *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + y) * W + x) * ctot + blk * C + 4 * q);
         *reinterpret_cast<f32x4*>(&tile[p * ld + blk * CP + 4 * q]) = v;
+    }
+}
+
+// Split form of load_window for a C-channel tensor (nblk == 1, C == CP): fetch into registers now, write the LDS tile later.
+// A persistent wave issues the fetch of its NEXT window before it starts on the current one, so the global round trip
+// (2-3k cycles under load, a fifth of a window's whole processing time) runs behind ~10k cycles of compute.
+template <int C>
+__device__ __forceinline__ void fetch_window(f32x4 (&r)[C / 16], const float* __restrict__ src, int H, int W, int n, int wy, int wx, int lane) {
+    constexpr int qpb = C / 4;
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int e = lane + 64 * k, q = e % qpb, p = e / qpb;
+        const int y = 4 * wy + (p >> 2), x = 4 * wx + (p & 3);
+        r[k] = *reinterpret_cast<const f32x4*>(src + (((size_t)n * H + y) * W + x) * C + 4 * q);
+    }
+}
+template <int C>
+__device__ __forceinline__ void put_window(const f32x4 (&r)[C / 16], float* tile, int ld, int lane) {
+    constexpr int qpb = C / 4;
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int e = lane + 64 * k, q = e % qpb, p = e / qpb;
+        *reinterpret_cast<f32x4*>(&tile[p * ld + 4 * q]) = r[k];
     }
 }
 
@@ -305,7 +334,7 @@ __device__ __forceinline__ void fused_forward_tiles(float* sm, const float* __re
     typedef AttnTiles<C> T;
     constexpr int NF = F::NF;
     const int i = lane & 15, g = lane >> 4;
-    load_window<C>(x, sm + F::XS, F::LDX, 1, C, H, W, n, wy, wx, lane);
+    if (x) load_window<C>(x, sm + F::XS, F::LDX, 1, C, H, W, n, wy, wx, lane);  // x == nullptr: the caller has filled Xs already
     WAVE_SYNC();
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
@@ -339,10 +368,20 @@ __global__ __launch_bounds__(64) void attn_fused_fwd_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
     const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    f32x4 xr[C / 16];
+    if ((int)blockIdx.x < nwin) {
+        const int w = blockIdx.x;
+        fetch_window<C>(xr, x, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
+    }
     for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
         const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
         WAVE_SYNC();
-        fused_forward_tiles<C>(sm, x, wqkv, bqkv, H, W, n, wy, wx, lane);
+        put_window<C>(xr, sm + F::XS, F::LDX, lane);
+        {
+            const int w2 = w + gridDim.x < nwin ? w + gridDim.x : w;  // next window of this wave (re-fetch the same one at the end)
+            fetch_window<C>(xr, x, H, W, w2 / (nwx * nwy), (w2 / nwx) % nwy, w2 % nwx, lane);
+        }
+        fused_forward_tiles<C>(sm, nullptr, wqkv, bqkv, H, W, n, wy, wx, lane);
         // Y^T[co][p] = sum_c Wp[co][c] O[p][c] + b : rows = channels -> one 16-byte store per lane and fragment
         f32x4 yv[NF][1];
         tile_zero<NF, 1>(yv);
@@ -388,11 +427,27 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) gbp[nf] = 0.f;
 
-    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+    f32x4 xr[C / 16], dyr[C / 16];
+    if ((int)blockIdx.x < nwin) {
+        const int w = blockIdx.x;
+        fetch_window<C>(dyr, dy, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
+        fetch_window<C>(xr, x, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
+    }
+    int wcount = 0;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x, ++wcount) {
         const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
         WAVE_SYNC();
-        load_window<C>(dy, dYs, F::LDX, 1, C, H, W, n, wy, wx, lane);
-        fused_forward_tiles<C>(sm, x, wqkv, bqkv, H, W, n, wy, wx, lane);  // Xs, q^, k^, v, P, inverse norms, Os
+        ATT_STAMP(0)
+        put_window<C>(dyr, dYs, F::LDX, lane);
+        put_window<C>(xr, sm + F::XS, F::LDX, lane);
+        {
+            const int w2 = w + gridDim.x < nwin ? w + gridDim.x : w;  // next window of this wave: in flight behind this one's compute
+            const int n2 = w2 / (nwx * nwy), wy2 = (w2 / nwx) % nwy, wx2 = w2 % nwx;
+            fetch_window<C>(dyr, dy, H, W, n2, wy2, wx2, lane);
+            fetch_window<C>(xr, x, H, W, n2, wy2, wx2, lane);
+        }
+        fused_forward_tiles<C>(sm, nullptr, wqkv, bqkv, H, W, n, wy, wx, lane);  // Xs (filled above), q^, k^, v, P, inverse norms, Os
+        ATT_STAMP(1)
 
         // ---- proj backward: dO = dY Wp ; dWp += dY^T O ; dbp += colsum(dY) --------------------------------------------
         {
@@ -407,6 +462,7 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
                 for (int r = 0; r < 4; ++r) gbp[nf] += dYs[(4 * g + r) * F::LDX + 16 * nf + i];
         }
         WAVE_SYNC();
+        ATT_STAMP(2)
         // ---- attention core backward (same algebra as attn_core_bwd_kernel), results into the dQKV tile -------------------
         f32x4 ds[NF][NF];
         tile_zero<NF, NF>(ds);
@@ -433,6 +489,7 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
             tile_store<1, NF>(dv, dQKV + 2 * C, T::LDQ, 1, lane);
         }
         WAVE_SYNC();
+        ATT_STAMP(3)
         tile_store<NF, NF>(ds, Ps, T::LDP, 1, lane);  // P <- dS
         WAVE_SYNC();
 #pragma unroll
@@ -457,6 +514,7 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
             }
         }
         WAVE_SYNC();
+        ATT_STAMP(4)
         // ---- qkv conv backward: dX = dQKV Wqkv ; dWqkv += dQKV^T X ; dbqkv += colsum(dQKV) --------------------------------
         {
             f32x4 d[NF][1];  // dX^T[ci][p] = sum_j Wqkv[j][ci] dQKV[p][j]
@@ -475,6 +533,8 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) gbq[b][nf] += dQKV[(4 * g + r) * T::LDQ + b * C + 16 * nf + i];
         }
+        ATT_STAMP(5)
+        ATT_STAMP(6)
     }
     // ---- this wave's slab: dWqkv (3C x C) | dWp (C x C) | dbqkv (3C) | dbp (C) ---------------------------------------------
     float* out = partial + (size_t)blockIdx.x * F::SLAB;
@@ -822,6 +882,11 @@ extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, flo
     return launch_attn_blk<256>(true, qkv, d_o, dqkv, N, H, W, C, st);
 }
 
+#ifdef MSTG_STAMPS
+extern "C" int mstg_debug_stamps_attn(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+#endif
 extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32; }
 
 extern "C" int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
