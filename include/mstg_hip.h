@@ -154,10 +154,11 @@ size_t mstg_msblock_fwd_workspace_bytes(int CH);
 int mstg_msblock_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
                      const float* b3, const float* w4, const float* b4, float* y, int N, int H, int W, int CH, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* input gradient of the four branches: dy (N,H,W,CH) -> dx (N,H,W,CH), written once (no accumulation passes) */
+/* input gradient of the four branches: dy (N,H,W,CH) -> dx (N,H,W,CH), written once (no accumulation passes);
+ * dres (nullable, (N,H,W,CH)) = gradient arriving over the block's residual connection (`+ x`, :84), added in the epilogue */
 size_t mstg_msblock_dgrad_workspace_bytes(int CH);
-int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, float* dx, int N,
-                       int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);
+int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, const float* dres,
+                       float* dx, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);
 size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH);
 int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
                        float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);

@@ -74,10 +74,10 @@ class MultiScaleBlock(nn.Module):
         wb = []
         for br in (self.branch1, self.branch2, self.branch3, self.branch4):
             wb += [br[0].weight, br[0].bias]
-        cat = ops.MSBranchesFn.apply(x, *wb)          # 4 convs -> one (N,H,W,ch) buffer, no torch.cat
+        cat, xres = ops.MSBranchesFn.apply(x, *wb)    # 4 convs -> one (N,H,W,ch) buffer, no torch.cat; xres = x for the residual
         cat = ops.instnorm_act(cat, ACT_RELU)          # per-channel IN: one launch covers all four branches
         f = self.fusion[0](cat, nhwc=True)
-        return ops.instnorm_act(f, ACT_RELU, residual=x)
+        return ops.instnorm_act(f, ACT_RELU, residual=xres)
 
     def forward(self, x):
         return to_nchw(self.forward_nhwc(to_nhwc(x)))

@@ -310,8 +310,9 @@ __device__ __forceinline__ void ms_dgrad_chunk(ACC& acc, const float* __restrict
 }
 
 template <int CH>
-__global__ __launch_bounds__(256) void ms_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wp, float* __restrict__ dx,
-                                                       int N, int H, int W, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void ms_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wp,
+                                                       const float* __restrict__ dres, float* __restrict__ dx, int N, int H, int W,
+                                                       int tiles_x, int tiles_y) {
     constexpr int NFW = CH / 16, PF = 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;
@@ -338,9 +339,13 @@ __global__ __launch_bounds__(256) void ms_dgrad_kernel(const float* __restrict__
     for (int pf = 0; pf < PF; ++pf) {
         const int gy = ty0 * MS_TH + PF * wave + pf, gx = tx0 * 16 + i;
         if (gy < H && gx < W) {
-            float* p = dx + (((size_t)n * H + gy) * W + gx) * CH + 4 * g;
+            const size_t o = (((size_t)n * H + gy) * W + gx) * CH + 4 * g;
 #pragma unroll
-            for (int wf = 0; wf < NFW; ++wf) *reinterpret_cast<f32x4*>(p + 16 * wf) = acc[wf][pf];
+            for (int wf = 0; wf < NFW; ++wf) {
+                f32x4 v = acc[wf][pf];
+                if (dres) v += *reinterpret_cast<const f32x4*>(dres + o + 16 * wf);  // gradient of the block's residual path
+                *reinterpret_cast<f32x4*>(dx + o + 16 * wf) = v;
+            }
         }
     }
 }
@@ -442,8 +447,8 @@ static size_t ms_dgrad_ws_floats() {
 }
 
 template <int CH>
-static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, float* dx, int N, int H, int W, void* ws, size_t ws_bytes,
-                           hipStream_t st) {
+static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, const float* dres, float* dx, int N, int H, int W, void* ws,
+                           size_t ws_bytes, hipStream_t st) {
     const size_t need = ms_dgrad_ws_floats<CH>() * sizeof(float);
     if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_dgrad: workspace too small");
     float* wp = (float*)ws;
@@ -451,8 +456,8 @@ static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, float* dx, i
     MSTG_CHECK_LAUNCH("ms_pack_dgrad_kernel");
     const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
     const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
-    hipLaunchKernelGGL((ms_dgrad_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, dy, (const float*)wp, dx, N, H, W, tiles_x,
-                       tiles_y);
+    hipLaunchKernelGGL((ms_dgrad_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, dy, (const float*)wp, dres, dx, N, H, W,
+                       tiles_x, tiles_y);
     MSTG_CHECK_LAUNCH("ms_dgrad_kernel");
     return MSTG_OK;
 }
@@ -468,16 +473,16 @@ extern "C" size_t mstg_msblock_dgrad_workspace_bytes(int CH) {
     return 0;
 }
 
-extern "C" int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, float* dx, int N,
-                                  int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, const float* dres,
+                                  float* dx, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !dx || !w1 || !w2 || !w3 || !w4) return fail_arg(MSTG_E_BADARG, "msblock_dgrad: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "msblock_dgrad: bad shape");
     if ((uint64_t)H * W * CH >= (1ull << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "msblock_dgrad: one image must stay below 2^30 elements");
     MsParamPtrs prm{{w1, w2, w3, w4}, {nullptr, nullptr, nullptr, nullptr}};
     hipStream_t st = (hipStream_t)stream;
-    if (CH == 16) return launch_ms_dgrad<16>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
-    if (CH == 32) return launch_ms_dgrad<32>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
-    if (CH == 64) return launch_ms_dgrad<64>(dy, prm, dx, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 16) return launch_ms_dgrad<16>(dy, prm, dres, dx, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 32) return launch_ms_dgrad<32>(dy, prm, dres, dx, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 64) return launch_ms_dgrad<64>(dy, prm, dres, dx, N, H, W, workspace, workspace_bytes, st);
     return fail_arg(MSTG_E_UNSUPPORTED, "msblock_dgrad: fused path exists for 16, 32 and 64 channels");
 }
 

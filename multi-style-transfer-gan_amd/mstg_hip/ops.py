@@ -237,13 +237,17 @@ class MSBranchesFn(torch.autograd.Function):
                 conv_fwd_raw(d, x, ws[j], bs[j], y)
         ctx.dims = (N, H, W, ch, c4)
         ctx.save_for_backward(x, *ws)
-        return y
+        # second output: x itself, for the block's residual connection.  Routing the residual through this Function brings its
+        # gradient into backward() below, where the fused dgrad kernel adds it in its epilogue instead of autograd running a
+        # separate full-tensor add.
+        return y, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         N, H, W, ch, c4 = ctx.dims
         x, *ws = ctx.saved_tensors
         dy = _req(dy, "multi-scale grad_output")
+        dres = None if dres is None else _req(dres, "multi-scale residual grad")
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         lib = _lib.load()
         fused = os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch
@@ -251,8 +255,9 @@ class MSBranchesFn(torch.autograd.Function):
         if fused and dx is not None:  # dx of all four branches in one pass over dy, written once
             wsd = _ws(lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
             _timed(f"ms_dgrad_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
-                   lambda: _lib.check(lib.mstg_msblock_dgrad(_p(dy), *[_p(t) for t in ws], _p(dx), N, H, W, ch, _p(wsd), wsd.numel() * 4,
-                                                             _stream()), "mstg_msblock_dgrad"), f"ms-dgrad N{N} {H}x{W} ch{ch}")
+                   lambda: _lib.check(lib.mstg_msblock_dgrad(_p(dy), *[_p(t) for t in ws], _p(dres), _p(dx), N, H, W, ch, _p(wsd),
+                                                             wsd.numel() * 4, _stream()), "mstg_msblock_dgrad"),
+                   f"ms-dgrad N{N} {H}x{W} ch{ch}")
         for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
             d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4, accumulate=int(j > 0))
             if dx is not None and not fused:
@@ -263,6 +268,10 @@ class MSBranchesFn(torch.autograd.Function):
                 d.accumulate = 0
                 conv_wgrad_raw(d, x, dy, dw, db)
             grads += [dw, db]
+        if dx is not None and dres is not None and not fused:
+            dx.add_(dres)
+        if dx is None and dres is not None:
+            dx = dres
         if fused:  # all eight parameter gradients in one pass over x and dy
             wsb = _ws(lib.mstg_msblock_wgrad_workspace_bytes(N, H, W, ch), x.device)
             _timed(f"wgrad_ms_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),

@@ -179,17 +179,19 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
     outs = [F.conv2d(xr, wr[0], br[0])] + [F.conv2d(xr, wr[j], br[j], padding=d, dilation=d) for j, d in ((1, 1), (2, 2), (3, 4))]
     yr = torch.cat(outs, 1)
     gy = rnd(tuple(yr.shape), 20)
-    gr = torch.autograd.grad((yr * gy).sum(), [xr] + wr + br)
+    gres = rnd(tuple(x.shape), 21)  # gradient arriving over the block's residual connection (second output = x itself)
+    gr = torch.autograd.grad((yr * gy).sum() + (xr * gres).sum(), [xr] + wr + br)
     xg = nhwc(x).to(DEV).requires_grad_(True)
     wg = [t.to(DEV).requires_grad_(True) for t in ws]
     bg = [t.to(DEV).requires_grad_(True) for t in bs]
     args = []
     for a, b in zip(wg, bg):
         args += [a, b]
-    yg = ops.MSBranchesFn.apply(xg, *args)
-    gg = torch.autograd.grad((yg * nhwc(gy).to(DEV)).sum(), [xg] + wg + bg)
+    yg, xa = ops.MSBranchesFn.apply(xg, *args)
+    assert xa.data_ptr() == xg.data_ptr()
+    gg = torch.autograd.grad((yg * nhwc(gy).to(DEV)).sum() + (xa * nhwc(gres).to(DEV)).sum(), [xg] + wg + bg)
     report("msbranches y", rel_l2(nchw(yg), yr), 2e-5)
-    report("msbranches dx (4 accumulated dgrads)", rel_l2(nchw(gg[0]), gr[0]), 2e-5)
+    report("msbranches dx (4 dgrads + residual gradient)", rel_l2(nchw(gg[0]), gr[0]), 2e-5)
     for j in range(4):
         report(f"msbranches dw{j + 1}", rel_l2(gg[1 + j], gr[1 + j]), 1e-4)
         report(f"msbranches db{j + 1}", rel_l2(gg[5 + j], gr[5 + j]), 1e-4)

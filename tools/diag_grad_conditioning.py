@@ -60,7 +60,7 @@ with torch.no_grad():
     wb = []
     for br in (msb.branch1, msb.branch2, msb.branch3, msb.branch4):
         wb += [br[0].weight, br[0].bias]
-    cat = ops.MSBranchesFn.apply(g, *wb)
+    cat, _ = ops.MSBranchesFn.apply(g, *wb)
     pre_hip = ops.instnorm_act(cat, 0).permute(0, 3, 1, 2).cpu().double()
 flips = (pre_hip > 0) != (pre64 > 0)
 print(f"== down2.4 normalised branch outputs: max|hip - f64| {float((pre_hip - pre64).abs().max()):.2e}; ReLU-mask flips: {int(flips.sum())} of {flips.numel()}")
