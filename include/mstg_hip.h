@@ -167,10 +167,11 @@ int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, 
  * fwd: training != 0 runs the one power iteration in place on u (M) and v (K); always sigma = u.(W v), w_out = w / sigma.
  * bwd: dw = dwn / sigma - (sum(dwn * w) / sigma^2) u v^T with the u, v, sigma of that forward (the caller keeps copies:
  * the next forward moves u and v on). */
+size_t mstg_spectral_norm_workspace_bytes(int M, int K); /* scratch of the multi-workgroup path (matrices >= 32768 elements) */
 int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, int M, int K, float eps,
-                           int training, void* stream);
+                           int training, void* workspace, size_t workspace_bytes, void* stream);
 int mstg_spectral_norm_bwd(const float* dwn, const float* w, const float* u, const float* v, const float* sigma, float* dw,
-                           int M, int K, void* stream);
+                           int M, int K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Build-defined multi-style perceptual loss pieces.  The reference has NO implementation of them (the

@@ -603,8 +603,10 @@ class SpectralNormFn(torch.autograd.Function):
             raise RuntimeError(f"mstg_hip spectral_norm: u/v sizes {u.numel()}/{v.numel()} do not match weight {tuple(w.shape)}")
         out = torch.empty_like(w)
         sigma = torch.empty(1, dtype=torch.float32, device=w.device)
-        _lib.check(_lib.load().mstg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(out), _p(sigma), M, K, float(eps), int(bool(training)),
-                                                      _stream()), "mstg_spectral_norm_fwd")
+        lib = _lib.load()
+        ws = _ws(lib.mstg_spectral_norm_workspace_bytes(M, K), w.device)
+        _lib.check(lib.mstg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(out), _p(sigma), M, K, float(eps), int(bool(training)),
+                                              _p(ws), ws.numel() * 4, _stream()), "mstg_spectral_norm_fwd")
         # the buffers move on at the next forward; this call's backward needs the values it produced
         ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
         ctx.dims = (M, K)
@@ -616,7 +618,9 @@ class SpectralNormFn(torch.autograd.Function):
         M, K = ctx.dims
         dwn = _req(dwn, "spectral_norm grad_output")
         dw = torch.empty_like(w)
-        _lib.check(_lib.load().mstg_spectral_norm_bwd(_p(dwn), _p(w), _p(u), _p(v), _p(sigma), _p(dw), M, K, _stream()),
+        lib = _lib.load()
+        ws = _ws(lib.mstg_spectral_norm_workspace_bytes(M, K), w.device)
+        _lib.check(lib.mstg_spectral_norm_bwd(_p(dwn), _p(w), _p(u), _p(v), _p(sigma), _p(dw), M, K, _p(ws), ws.numel() * 4, _stream()),
                    "mstg_spectral_norm_bwd")
         return dw, None, None, None, None
 
