@@ -67,7 +67,8 @@ int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, con
 /* dx = d(loss)/d(module input), from dy = d(loss)/d(module output) */
 int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
                       size_t workspace_bytes, void* stream);
-/* dw (same layout as w) and dbias (nullable) ; workspace holds per-split partial sums (deterministic, no atomics) */
+/* dw (same layout as w) and dbias (nullable) ; workspace holds per-split partial sums (deterministic, no atomics);
+ * d->accumulate != 0: dw += and dbias += (gradients accumulated straight into an optimizer's flat gradient buffer) */
 size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias /*nullable*/,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -161,17 +162,19 @@ int mstg_msblock_dgrad(const float* dy, const float* w1, const float* w2, const 
                        float* dx, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);
 size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH);
 int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
-                       float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, void* stream);
+                       float* dw4, float* db4, int accumulate /* != 0: add to what the eight buffers hold */, int N, int H, int W,
+                       int CH, void* workspace, size_t workspace_bytes, void* stream);
 
 /* torch.nn.utils.spectral_norm on a conv weight seen as an (M = Cout, K = Cin*kh*kw) matrix (enhanced_generator.py:269-271).
  * fwd: training != 0 runs the one power iteration in place on u (M) and v (K); always sigma = u.(W v), w_out = w / sigma.
  * bwd: dw = dwn / sigma - (sum(dwn * w) / sigma^2) u v^T with the u, v, sigma of that forward (the caller keeps copies:
  * the next forward moves u and v on). */
 size_t mstg_spectral_norm_workspace_bytes(int M, int K); /* scratch of the multi-workgroup path (matrices >= 32768 elements) */
-int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, int M, int K, float eps,
-                           int training, void* workspace, size_t workspace_bytes, void* stream);
+/* u_save / v_save (nullable): copies of the u, v this call ends with, for that call's backward */
+int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, float* u_save, float* v_save, int M,
+                           int K, float eps, int training, void* workspace, size_t workspace_bytes, void* stream);
 int mstg_spectral_norm_bwd(const float* dwn, const float* w, const float* u, const float* v, const float* sigma, float* dw,
-                           int M, int K, void* workspace, size_t workspace_bytes, void* stream);
+                           int accumulate /* != 0: dw += */, int M, int K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Build-defined multi-style perceptual loss pieces.  The reference has NO implementation of them (the

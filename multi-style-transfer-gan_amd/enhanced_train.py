@@ -107,6 +107,12 @@ class EnhancedCycleGAN:
                 dp.broadcast_(b)
 
     def train_step_async(self, real_A, real_B):
+        # parameter gradients go straight into the two flat gradient buffers (ops.direct_param_grads), not through autograd's
+        # accumulation kernels
+        with ops.direct_param_grads():
+            return self._train_step_async(real_A, real_B)
+
+    def _train_step_async(self, real_A, real_B):
         G_AB, G_BA, D_A, D_B = self.G_AB, self.G_BA, self.D_A, self.D_B
         nb = real_A.shape[0]
         if self.batch_generator_passes:

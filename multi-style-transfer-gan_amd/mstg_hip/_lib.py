@@ -64,10 +64,10 @@ SIGNATURES = {
     "mstg_msblock_dgrad_workspace_bytes": (_sz, [_i]),
     "mstg_msblock_dgrad": (_i, [_fp] * 7 + [_i, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_msblock_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "mstg_msblock_wgrad": (_i, [_fp] * 10 + [_i, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_msblock_wgrad": (_i, [_fp] * 10 + [_i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_spectral_norm_workspace_bytes": (_sz, [_i, _i]),
-    "mstg_spectral_norm_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _i, _i, _f, _i, _vp, _sz, _vp]),
-    "mstg_spectral_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _vp, _sz, _vp]),
+    "mstg_spectral_norm_fwd": (_i, [_fp] * 7 + [_i, _i, _f, _i, _vp, _sz, _vp]),
+    "mstg_spectral_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -513,7 +513,7 @@ static int wgrad_1x1_splits(const WGradArgs& a) {
 // fixed order, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            float* __restrict__ dbias, int S, int T, int Cg, int Ch, int s_g,
-                                                           int s_h, int pstride) {
+                                                           int s_h, int pstride, int accumulate) {
     __shared__ float sh[16][17];
     const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
     const int total = T * Cg * Ch, nout = pstride;
@@ -529,9 +529,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int k = 0; k < 16; ++k) r += sh[k][e];
         if (idx < total) {
             const int hch = idx % Ch, gch = (idx / Ch) % Cg, t = idx / (Ch * Cg);
-            dw[(size_t)gch * s_g + (size_t)hch * s_h + t] = r;
+            float* o = dw + (size_t)gch * s_g + (size_t)hch * s_h + t;
+            *o = accumulate ? *o + r : r;
         } else if (dbias) {
-            dbias[idx - total] = r;
+            dbias[idx - total] = accumulate ? dbias[idx - total] + r : r;
         }
     }
 }
@@ -757,7 +758,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
     const int pstride = total + (a.with_bias ? a.Ch : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
-                       pstride);
+                       pstride, d->accumulate);
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;
 }

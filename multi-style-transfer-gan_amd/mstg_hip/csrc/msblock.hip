@@ -358,7 +358,7 @@ struct MsGradPtrs {
 // fixed-order sum over the S partial slabs, then scatter: slab index -> (branch, out channel, in channel, tap) of the four
 // PyTorch-layout gradients  dw1 (C4, CH, 1, 1), dw2..4 (C4, CH, 3, 3)  and  db1..4 (C4)
 template <int CH>
-__global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __restrict__ partial, MsGradPtrs out, int S) {
+__global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __restrict__ partial, MsGradPtrs out, int S, int accumulate) {
     constexpr int NFH = CH / 16, C4 = CH / 4, U = NFH + 24, NG = CH / 16, NACC = NG * U * 256, PSTRIDE = NACC + CH;
     __shared__ float sh[16][17];
     const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
@@ -374,19 +374,23 @@ __global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __res
     for (int k = 0; k < 16; ++k) r += sh[k][e];
     if (idx >= NACC) {  // bias gradient of output channel co
         const int co = idx - NACC;
-        out.db[co / C4][co % C4] = r;
+        float* o = &out.db[co / C4][co % C4];
+        *o = accumulate ? *o + r : r;
         return;
     }
     const int n = idx & 15, m = (idx >> 4) & 15, u = (idx >> 8) % U, gch = idx / (U * 256);
     const int ci = 16 * gch + m;
     if (u < NFH) {  // centre tap, fragment u
         const int co = 16 * u + n, j = co / C4, cj = co % C4;
-        if (j == 0) out.dw[0][cj * CH + ci] = r;
-        else out.dw[j][(cj * CH + ci) * 9 + 4] = r;
+        float* o = j == 0 ? &out.dw[0][cj * CH + ci] : &out.dw[j][(cj * CH + ci) * 9 + 4];
+        *o = accumulate ? *o + r : r;
     } else {
         const int rr = (u - NFH) >> 3, i8 = (u - NFH) & 7, t9 = i8 < 4 ? i8 : i8 + 1, j = rr + 1;
         const int co = 16 * ((j * C4) / 16) + n;
-        if (co >= j * C4 && co < (j + 1) * C4) out.dw[j][((co - j * C4) * CH + ci) * 9 + t9] = r;
+        if (co >= j * C4 && co < (j + 1) * C4) {
+            float* o = &out.dw[j][((co - j * C4) * CH + ci) * 9 + t9];
+            *o = accumulate ? *o + r : r;
+        }
     }
 }
 
@@ -403,8 +407,8 @@ static size_t ms_wgrad_plan(int N, int H, int W, int& S, int& tiles_x, int& tile
 }
 
 template <int CH>
-static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& out, int N, int H, int W, void* ws, size_t ws_bytes,
-                           hipStream_t st) {
+static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& out, int accumulate, int N, int H, int W, void* ws,
+                           size_t ws_bytes, hipStream_t st) {
     constexpr int NFH = CH / 16, U = NFH + 24, NG = CH / 16, PSTRIDE = NG * U * 256 + CH;
     int S, tiles_x, tiles_y, ntiles;
     const size_t need = ms_wgrad_plan<CH>(N, H, W, S, tiles_x, tiles_y, ntiles);
@@ -419,7 +423,7 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
     }
     hipLaunchKernelGGL((wgrad_ms_kernel<CH>), dim3(S, NG, 1), dim3(256), lds, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
     MSTG_CHECK_LAUNCH("wgrad_ms_kernel");
-    hipLaunchKernelGGL((wgrad_ms_reduce_kernel<CH>), dim3(cdiv(PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S);
+    hipLaunchKernelGGL((wgrad_ms_reduce_kernel<CH>), dim3(cdiv(PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S, accumulate);
     MSTG_CHECK_LAUNCH("wgrad_ms_reduce_kernel");
     return MSTG_OK;
 }
@@ -517,15 +521,15 @@ extern "C" size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH
 }
 
 extern "C" int mstg_msblock_wgrad(const float* x, const float* dy, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3,
-                                  float* dw4, float* db4, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+                                  float* dw4, float* db4, int accumulate, int N, int H, int W, int CH, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw1 || !db1 || !dw2 || !db2 || !dw3 || !db3 || !dw4 || !db4) return fail_arg(MSTG_E_BADARG, "msblock_wgrad: null pointer");
     if (N <= 0 || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "msblock_wgrad: bad shape");
     if ((uint64_t)H * W * CH >= (1ull << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "msblock_wgrad: one image must stay below 2^30 elements");
     MsGradPtrs out{{dw1, dw2, dw3, dw4}, {db1, db2, db3, db4}};
     hipStream_t st = (hipStream_t)stream;
-    if (CH == 16) return launch_ms_wgrad<16>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
-    if (CH == 32) return launch_ms_wgrad<32>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
-    if (CH == 64) return launch_ms_wgrad<64>(x, dy, out, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 16) return launch_ms_wgrad<16>(x, dy, out, accumulate, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 32) return launch_ms_wgrad<32>(x, dy, out, accumulate, N, H, W, workspace, workspace_bytes, st);
+    if (CH == 64) return launch_ms_wgrad<64>(x, dy, out, accumulate, N, H, W, workspace, workspace_bytes, st);
     return fail_arg(MSTG_E_UNSUPPORTED, "msblock_wgrad: fused path exists for 16, 32 and 64 channels");
 }

@@ -31,7 +31,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {  // all t
 // W: (M, K) row-major (= weight.view(Cout, -1)); LDS: su[M] | sv[K] | red[32]
 __global__ __launch_bounds__(1024) void spectral_norm_fwd_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
                                                                  float* __restrict__ Wn, float* __restrict__ sigma_out, int M, int K,
-                                                                 float eps, int training) {
+                                                                 float eps, int training, float* __restrict__ u_save,
+                                                                 float* __restrict__ v_save) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* su = sm;
     float* sv = sm + M;
@@ -58,6 +59,8 @@ __global__ __launch_bounds__(1024) void spectral_norm_fwd_kernel(const float* __
         }
         __syncthreads();
     }
+    if (v_save)
+        for (int k = tid; k < K; k += nt) v_save[k] = sv[k];
     // s = W v (one wave per row)
     __shared__ float s_rows[4096];
     for (int m = wave; m < M; m += nw) {
@@ -75,10 +78,14 @@ __global__ __launch_bounds__(1024) void spectral_norm_fwd_kernel(const float* __
         for (int m = tid; m < M; m += nt) {
             const float un = s_rows[m] / nu;
             u[m] = un;
+            if (u_save) u_save[m] = un;
             sig_part = fmaf(un, s_rows[m], sig_part);
         }
     } else {
-        for (int m = tid; m < M; m += nt) sig_part = fmaf(su[m], s_rows[m], sig_part);
+        for (int m = tid; m < M; m += nt) {
+            sig_part = fmaf(su[m], s_rows[m], sig_part);
+            if (u_save) u_save[m] = su[m];
+        }
     }
     const float sigma = block_sum_1024(sig_part, red);
     if (tid == 0) *sigma_out = sigma;
@@ -88,7 +95,8 @@ __global__ __launch_bounds__(1024) void spectral_norm_fwd_kernel(const float* __
 
 __global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const float* __restrict__ dWn, const float* __restrict__ W,
                                                                  const float* __restrict__ u, const float* __restrict__ v,
-                                                                 const float* __restrict__ sigma_p, float* __restrict__ dW, int M, int K) {
+                                                                 const float* __restrict__ sigma_p, float* __restrict__ dW, int M, int K,
+                                                                 int accumulate) {
     __shared__ float red[32];
     const int tid = threadIdx.x, nt = blockDim.x;
     const size_t total = (size_t)M * K;
@@ -99,7 +107,8 @@ __global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const float* __
     const float c = dot / (sigma * sigma);
     for (size_t e = tid; e < total; e += nt) {
         const int m = (int)(e / K), k = (int)(e - (size_t)m * K);
-        dW[e] = dWn[e] / sigma - c * u[m] * v[k];
+        const float r = dWn[e] / sigma - c * u[m] * v[k];
+        dW[e] = accumulate ? dW[e] + r : r;
     }
 }
 
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(256) void spectral_a_kernel(const float* __restrict
 // B: every workgroup rebuilds t = sum_b tpart[b] and v = t / max(||t||, eps) (workgroup 0 stores v), then s[m] = W[m] . v for
 // its own rows
 __global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict__ W, float* __restrict__ v, float* __restrict__ scratch,
-                                                         int M, int K, float eps, int training) {
+                                                         int M, int K, float eps, int training, float* __restrict__ v_save) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // sv[K] | red[32]
     float* sv = sm;
     float* red = sm + K;
@@ -150,6 +159,8 @@ __global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict
         }
     }
     __syncthreads();
+    if (v_save && blockIdx.x == 0)
+        for (int k = tid; k < K; k += 256) v_save[k] = sv[k];
     const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G, m0 = b * rows, m1 = min(M, m0 + rows);
     float* s_out = scratch + (size_t)SN_G * K;
     for (int m = m0 + wave; m < m1; m += 4) {
@@ -164,7 +175,7 @@ __global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict
 // keeps u), then writes its rows of W / sigma
 __global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict__ W, float* __restrict__ u, const float* __restrict__ scratch,
                                                          float* __restrict__ Wn, float* __restrict__ sigma_out, int M, int K, float eps,
-                                                         int training) {
+                                                         int training, float* __restrict__ u_save) {
     __shared__ float red[32];
     const float* s_in = scratch + (size_t)SN_G * K;
     const int tid = threadIdx.x;
@@ -176,13 +187,19 @@ __global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict
         float sp = 0.f;
         for (int m = tid; m < M; m += 256) {
             const float un = s_in[m] / nu;
-            if (blockIdx.x == 0) u[m] = un;
+            if (blockIdx.x == 0) {
+                u[m] = un;
+                if (u_save) u_save[m] = un;
+            }
             sp = fmaf(un, s_in[m], sp);
         }
         sigma = block_sum_1024(sp, red);
     } else {
         float sp = 0.f;
-        for (int m = tid; m < M; m += 256) sp = fmaf(u[m], s_in[m], sp);
+        for (int m = tid; m < M; m += 256) {
+            sp = fmaf(u[m], s_in[m], sp);
+            if (u_save && blockIdx.x == 0) u_save[m] = u[m];
+        }
         sigma = block_sum_1024(sp, red);
     }
     if (blockIdx.x == 0 && tid == 0) *sigma_out = sigma;
@@ -204,7 +221,8 @@ __global__ __launch_bounds__(256) void spectral_bwd_a_kernel(const float* __rest
 }
 __global__ __launch_bounds__(256) void spectral_bwd_b_kernel(const float* __restrict__ dWn, const float* __restrict__ u,
                                                              const float* __restrict__ v, const float* __restrict__ sigma_p,
-                                                             const float* __restrict__ scratch, float* __restrict__ dW, int M, int K) {
+                                                             const float* __restrict__ scratch, float* __restrict__ dW, int M, int K,
+                                                             int accumulate) {
     float dot = 0.f;
     for (int g = 0; g < SN_G; ++g) dot += scratch[g];
     const float sigma = *sigma_p, c = dot / (sigma * sigma);
@@ -212,7 +230,8 @@ __global__ __launch_bounds__(256) void spectral_bwd_b_kernel(const float* __rest
     const size_t e0 = (size_t)b * rows * K, e1 = min((size_t)M * K, e0 + (size_t)rows * K);
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
         const int m = (int)(e / K), k = (int)(e - (size_t)m * K);
-        dW[e] = dWn[e] / sigma - c * u[m] * v[k];
+        const float r = dWn[e] / sigma - c * u[m] * v[k];
+        dW[e] = accumulate ? dW[e] + r : r;
     }
 }
 
@@ -227,8 +246,8 @@ extern "C" size_t mstg_spectral_norm_workspace_bytes(int M, int K) {
 
 static bool spectral_multi(int M, int K) { return (size_t)M * K >= 32768 && M >= SN_G; }
 
-extern "C" int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, int M, int K, float eps,
-                                      int training, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, float* sigma, float* u_save, float* v_save, int M,
+                                      int K, float eps, int training, void* workspace, size_t workspace_bytes, void* stream) {
     if (!w || !u || !v || !w_out || !sigma) return fail_arg(MSTG_E_BADARG, "spectral_norm: null pointer");
     if (M <= 0 || K <= 0 || M > 4096 || K > 16384) return fail_arg(MSTG_E_UNSUPPORTED, "spectral_norm: matrix larger than 4096 x 16384");
     if (spectral_multi(M, K)) {
@@ -240,20 +259,21 @@ extern "C" int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float*
             hipLaunchKernelGGL(spectral_a_kernel, dim3(SN_G), dim3(256), 0, st, w, (const float*)u, scratch, M, K);
             MSTG_CHECK_LAUNCH("spectral_a_kernel");
         }
-        hipLaunchKernelGGL(spectral_b_kernel, dim3(SN_G), dim3(256), (size_t)(K + 64) * sizeof(float), st, w, v, scratch, M, K, eps, training);
+        hipLaunchKernelGGL(spectral_b_kernel, dim3(SN_G), dim3(256), (size_t)(K + 64) * sizeof(float), st, w, v, scratch, M, K, eps, training, v_save);
         MSTG_CHECK_LAUNCH("spectral_b_kernel");
-        hipLaunchKernelGGL(spectral_c_kernel, dim3(SN_G), dim3(256), 0, st, w, u, (const float*)scratch, w_out, sigma, M, K, eps, training);
+        hipLaunchKernelGGL(spectral_c_kernel, dim3(SN_G), dim3(256), 0, st, w, u, (const float*)scratch, w_out, sigma, M, K, eps, training, u_save);
         MSTG_CHECK_LAUNCH("spectral_c_kernel");
         return MSTG_OK;
     }
     const size_t lds = (size_t)(M + K + 64) * sizeof(float);
-    hipLaunchKernelGGL(spectral_norm_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, w, u, v, w_out, sigma, M, K, eps, training);
+    hipLaunchKernelGGL(spectral_norm_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, w, u, v, w_out, sigma, M, K, eps, training, u_save,
+                       v_save);
     MSTG_CHECK_LAUNCH("spectral_norm_fwd_kernel");
     return MSTG_OK;
 }
 
 extern "C" int mstg_spectral_norm_bwd(const float* dwn, const float* w, const float* u, const float* v, const float* sigma, float* dw,
-                                      int M, int K, void* workspace, size_t workspace_bytes, void* stream) {
+                                      int accumulate, int M, int K, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dwn || !w || !u || !v || !sigma || !dw) return fail_arg(MSTG_E_BADARG, "spectral_norm_bwd: null pointer");
     if (M <= 0 || K <= 0) return fail_arg(MSTG_E_BADARG, "spectral_norm_bwd: bad shape");
     if (spectral_multi(M, K)) {
@@ -263,11 +283,11 @@ extern "C" int mstg_spectral_norm_bwd(const float* dwn, const float* w, const fl
         hipStream_t st = (hipStream_t)stream;
         hipLaunchKernelGGL(spectral_bwd_a_kernel, dim3(SN_G), dim3(256), 0, st, dwn, w, scratch, M, K);
         MSTG_CHECK_LAUNCH("spectral_bwd_a_kernel");
-        hipLaunchKernelGGL(spectral_bwd_b_kernel, dim3(SN_G), dim3(256), 0, st, dwn, u, v, sigma, (const float*)scratch, dw, M, K);
+        hipLaunchKernelGGL(spectral_bwd_b_kernel, dim3(SN_G), dim3(256), 0, st, dwn, u, v, sigma, (const float*)scratch, dw, M, K, accumulate);
         MSTG_CHECK_LAUNCH("spectral_bwd_b_kernel");
         return MSTG_OK;
     }
-    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dwn, w, u, v, sigma, dw, M, K);
+    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dwn, w, u, v, sigma, dw, M, K, accumulate);
     MSTG_CHECK_LAUNCH("spectral_norm_bwd_kernel");
     return MSTG_OK;
 }

@@ -55,6 +55,34 @@ def make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed=0, x_n
                     Cin if x_ctot is None else x_ctot, x_coff, Cout if y_ctot is None else y_ctot, y_coff, act, int(accumulate))
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Parameter gradients straight into p.grad
+# ----------------------------------------------------------------------------------------------------------
+# With every p.grad a persistent view of an optimizer's flat gradient buffer (optim.FlatAdam), the reduce kernels can add a
+# parameter's gradient to that view themselves; backward() then returns None for the parameter and autograd launches no
+# `grad += new` kernel (about 350 of them per CycleGAN step).  Opt-in (EnhancedCycleGAN.train_step): torch.autograd.grad /
+# hooks on parameters do not see gradients delivered this way.
+_DIRECT_PARAM_GRADS = False
+
+
+class direct_param_grads:
+    def __enter__(self):
+        global _DIRECT_PARAM_GRADS
+        self.prev, _DIRECT_PARAM_GRADS = _DIRECT_PARAM_GRADS, True
+
+    def __exit__(self, *exc):
+        global _DIRECT_PARAM_GRADS
+        _DIRECT_PARAM_GRADS = self.prev
+        return False
+
+
+def _grad_slot(p):
+    """p.grad if gradients of the parameter `p` can be accumulated in place right now, else None."""
+    if not _DIRECT_PARAM_GRADS or not isinstance(p, torch.nn.Parameter) or p.grad is None or not p.grad.is_contiguous():
+        return None
+    return p.grad
+
+
 class KernelTimer:
     """Opt-in per-launch timing with HIP events on the launch stream (torch's current stream), used by bench.py for the
     roofline figure.  Each record: (kernel symbol, start event, end event, algorithmic flops, algorithmic bytes)."""
@@ -176,6 +204,7 @@ class ConvFn(torch.autograd.Function):
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
         conv_fwd_raw(d, x, w, b, y)
         ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
+        ctx.prefs = (w, b)  # the objects handed to apply(): nn.Parameters when the layer owns them (see _grad_slot)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 
@@ -195,10 +224,19 @@ class ConvFn(torch.autograd.Function):
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            if fuse_db:
-                db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
-            conv_wgrad_raw(d, x, dy, dw, db if fuse_db else None)
+            gw = _grad_slot(ctx.prefs[0])
+            gb = _grad_slot(ctx.prefs[1]) if fuse_db else None
+            if gw is not None and (gb is not None or not fuse_db):  # accumulate into p.grad, hand autograd nothing
+                d.accumulate = 1
+                conv_wgrad_raw(d, x, dy, gw, gb)
+                d.accumulate = 0
+                if fuse_db:
+                    want_db = False
+            else:
+                dw = torch.empty_like(w)
+                if fuse_db:
+                    db = torch.empty(Cout, dtype=torch.float32, device=dy.device)
+                conv_wgrad_raw(d, x, dy, dw, db if fuse_db else None)
         if want_db and not fuse_db:
             db = plane_sum_nchw(dy) if y_nchw else channel_sum(dy, N * Ho * Wo, Cout, 0, Cout)
         return dx, dw, db, None
@@ -236,6 +274,7 @@ class MSBranchesFn(torch.autograd.Function):
                 d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4)
                 conv_fwd_raw(d, x, ws[j], bs[j], y)
         ctx.dims = (N, H, W, ch, c4)
+        ctx.prefs = tuple(wb)
         ctx.save_for_backward(x, *ws)
         # second output: x itself, for the block's residual connection.  Routing the residual through this Function brings its
         # gradient into backward() below, where the fused dgrad kernel adds it in its epilogue instead of autograd running a
@@ -274,10 +313,15 @@ class MSBranchesFn(torch.autograd.Function):
             dx = dres
         if fused:  # all eight parameter gradients in one pass over x and dy
             wsb = _ws(lib.mstg_msblock_wgrad_workspace_bytes(N, H, W, ch), x.device)
+            slots = [_grad_slot(p) for p in ctx.prefs]
+            direct = all(t is not None for t in slots)
+            outs = slots if direct else grads
             _timed(f"wgrad_ms_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
-                   lambda: _lib.check(lib.mstg_msblock_wgrad(_p(x), _p(dy), *[_p(t) for t in grads], N, H, W, ch, _p(wsb),
+                   lambda: _lib.check(lib.mstg_msblock_wgrad(_p(x), _p(dy), *[_p(t) for t in outs], int(direct), N, H, W, ch, _p(wsb),
                                                              wsb.numel() * 4, _stream()), "mstg_msblock_wgrad"),
                    f"ms-wgrad N{N} {H}x{W} ch{ch}")
+            if direct:
+                grads = [None] * 8
         return (dx, *grads)
 
 
@@ -605,10 +649,16 @@ class SpectralNormFn(torch.autograd.Function):
         sigma = torch.empty(1, dtype=torch.float32, device=w.device)
         lib = _lib.load()
         ws = _ws(lib.mstg_spectral_norm_workspace_bytes(M, K), w.device)
-        _lib.check(lib.mstg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(out), _p(sigma), M, K, float(eps), int(bool(training)),
-                                              _p(ws), ws.numel() * 4, _stream()), "mstg_spectral_norm_fwd")
-        # the buffers move on at the next forward; this call's backward needs the values it produced
-        ctx.save_for_backward(w, u.clone(), v.clone(), sigma)
+        # the buffers move on at the next forward; this call's backward needs the values it produced (copies written by the
+        # kernel itself, and only when a backward can follow)
+        need = ctx.needs_input_grad[0]
+        us = torch.empty_like(u) if need else None
+        vs = torch.empty_like(v) if need else None
+        _lib.check(lib.mstg_spectral_norm_fwd(_p(w), _p(u), _p(v), _p(out), _p(sigma), _p(us), _p(vs), M, K, float(eps),
+                                              int(bool(training)), _p(ws), ws.numel() * 4, _stream()), "mstg_spectral_norm_fwd")
+        ctx.pref = w
+        if need:
+            ctx.save_for_backward(w, us, vs, sigma)
         ctx.dims = (M, K)
         return out
 
@@ -617,12 +667,13 @@ class SpectralNormFn(torch.autograd.Function):
         w, u, v, sigma = ctx.saved_tensors
         M, K = ctx.dims
         dwn = _req(dwn, "spectral_norm grad_output")
-        dw = torch.empty_like(w)
+        slot = _grad_slot(ctx.pref)
+        dw = slot if slot is not None else torch.empty_like(w)
         lib = _lib.load()
         ws = _ws(lib.mstg_spectral_norm_workspace_bytes(M, K), w.device)
-        _lib.check(lib.mstg_spectral_norm_bwd(_p(dwn), _p(w), _p(u), _p(v), _p(sigma), _p(dw), M, K, _p(ws), ws.numel() * 4, _stream()),
-                   "mstg_spectral_norm_bwd")
-        return dw, None, None, None, None
+        _lib.check(lib.mstg_spectral_norm_bwd(_p(dwn), _p(w), _p(u), _p(v), _p(sigma), _p(dw), int(slot is not None), M, K, _p(ws),
+                                              ws.numel() * 4, _stream()), "mstg_spectral_norm_bwd")
+        return (None if slot is not None else dw), None, None, None, None
 
 
 def install_fused_spectral_norm(module, name: str = "weight") -> bool:
