@@ -51,27 +51,38 @@ __device__ __forceinline__ void tile_store(const f32x4 (&acc)[MF][NF], float* Dp
             for (int r = 0; r < 4; ++r) Dp[(16 * mf + 4 * g + r) * d_sm + (16 * nf + i) * d_sn] = acc[mf][nf][r];
 }
 
-// sum over the 16 lanes that share lane>>4 (one accumulator row lives in 16 lanes)
+// Reductions over the 16 lanes that share lane >> 4 (one accumulator row lives in 16 lanes).  Written with DPP row operations
+// (quad_perm, row_half_mirror, row_mirror: VALU-speed cross-lane moves inside a row of 16): __shfl_xor compiles to
+// ds_bpermute_b32 here, a ~100-cycle LDS round trip per step, and the softmax / normalisation chains are four dependent
+// steps deep -- time stamps showed them to be 60 % of a 32-channel window's forward cycles.  Every lane ends with the result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
     return v;
 }
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64));
-    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
     return v;
 }
 
 #ifdef MSTG_STAMPS
 __device__ unsigned long long g_att_stamps[64 * 8];
 #define ATT_STAMP(k) if (threadIdx.x == 0 && wcount == 2 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 64) g_att_stamps[(blockIdx.x / 31) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+// inside the forward helpers (no window counter there): every window stamps, the last one stays
+__device__ unsigned long long g_att_fstamps[64 * 8];
+#define ATT_FSTAMP(k) if (threadIdx.x == 0 && (blockIdx.x % 31) == 0 && blockIdx.x / 31 < 64) g_att_fstamps[(blockIdx.x / 31) * 8 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define ATT_STAMP(k)
+#define ATT_FSTAMP(k)
 #endif
 #define WAVE_SYNC() __syncthreads() /* one-wave workgroup: orders this wave's LDS writes before its reads */
 
@@ -136,6 +147,7 @@ __device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
     float* qkv = sm + T::QKV;
     float* Ps = sm + T::P;
     float* invn = sm + T::INVN;
+    ATT_FSTAMP(2)
     // ---- L2 normalise q and k per pixel over channels (F.normalize: v / max(||v||, 1e-12)) ----------------------
     {
         float sq = 0.f, sk = 0.f;
@@ -155,6 +167,7 @@ __device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
         if (g == 0) { invn[i] = iq; invn[16 + i] = ik; }
     }
     WAVE_SYNC();
+    ATT_FSTAMP(3)
     // ---- S[c1][c2] = sum_p q^[p][c1] k^[p][c2] ; softmax over c2 (the 16 lanes of a row x NF fragments) ---------
     f32x4 s[NF][NF];
     tile_zero<NF, NF>(s);
@@ -184,6 +197,7 @@ __device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
     }
     tile_store<NF, NF>(s, Ps, T::LDP, 1, lane);
     WAVE_SYNC();
+    ATT_FSTAMP(4)
 }
 
 template <int CP>
@@ -334,8 +348,10 @@ __device__ __forceinline__ void fused_forward_tiles(float* sm, const float* __re
     typedef AttnTiles<C> T;
     constexpr int NF = F::NF;
     const int i = lane & 15, g = lane >> 4;
+    ATT_FSTAMP(0)
     if (x) load_window<C>(x, sm + F::XS, F::LDX, 1, C, H, W, n, wy, wx, lane);  // x == nullptr: the caller has filled Xs already
     WAVE_SYNC();
+    ATT_FSTAMP(1)
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
         f32x4 acc[1][NF];
@@ -357,6 +373,7 @@ __device__ __forceinline__ void fused_forward_tiles(float* sm, const float* __re
     tile_mma<NF, 1>(o, sm + T::P, T::LDP, 1, sm + T::QKV + 2 * C, 1, T::LDQ, C, lane);
     tile_store<NF, 1>(o, sm + F::OS, 1, F::LDX, lane);
     WAVE_SYNC();
+    ATT_FSTAMP(5)
 }
 
 template <int C>
@@ -885,6 +902,9 @@ extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, flo
 #ifdef MSTG_STAMPS
 extern "C" int mstg_debug_stamps_attn(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_stamps), sizeof(unsigned long long) * 64 * 8);
+}
+extern "C" int mstg_debug_stamps_attn_fwd(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_fstamps), sizeof(unsigned long long) * 64 * 8);
 }
 #endif
 extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32; }

@@ -27,3 +27,14 @@ for j in range(5):
     ds = [r[j + 1] - r[j] for r in rows]
     print(f"  {names[j]:32s} median {statistics.median(ds):8.0f}  min {min(ds):8.0f}  max {max(ds):8.0f}")
 print(f"  total {statistics.median([r[5] - r[0] for r in rows]):8.0f}")
+
+fn2 = ctypes.CDLL(_lib.LIB_PATH).mstg_debug_stamps_attn_fwd
+fn2.restype = ctypes.c_int; fn2.argtypes = [ctypes.c_void_p]
+assert fn2(buf) == 0
+rows = [[buf[i * 8 + j] for j in range(6)] for i in range(64)]
+rows = [r for r in rows if r[0] and r[5] > r[0]]
+names = ["x window -> LDS + sync", "qkv 1x1 conv (+bias, store)", "normalise q, k", "S = q^T k, softmax, store P", "O = P V, store"]
+print(f"forward tiles (last window of each sampled wave, inside the backward kernel):")
+for j in range(5):
+    ds = [r[j + 1] - r[j] for r in rows]
+    print(f"  {names[j]:32s} median {statistics.median(ds):8.0f}  min {min(ds):8.0f}  max {max(ds):8.0f}")
