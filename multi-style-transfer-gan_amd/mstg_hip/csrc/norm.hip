@@ -45,7 +45,19 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
     if (row < rows) {
         if (!BWD) {
             const f32x4 K = *reinterpret_cast<const f32x4*>((batch ? x : xb) + 4 * q);
-            for (int p = p0 + row; p < p1; p += rows) {
+            int p = p0 + row;
+            for (; p + 3 * rows < p1; p += 4 * rows) {
+                f32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(p + k * rows) * C + 4 * q);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 w = v[k] - K;
+                    s1 += w;
+                    s2 += w * w;
+                }
+            }
+            for (; p < p1; p += rows) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)p * C + 4 * q) - K;
                 s1 += v;
                 s2 += v * v;
@@ -57,7 +69,25 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
             for (int e = 0; e < 4; ++e) { mu[e] = st[(4 * q + e) * 2]; rs[e] = st[(4 * q + e) * 2 + 1]; }
             if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
             const float* dyb = dy + (size_t)n * g.HW * C;
-            for (int p = p0 + row; p < p1; p += rows) {
+            int p = p0 + row;
+            for (; p + 3 * rows < p1; p += 4 * rows) {
+                f32x4 xv[4], gv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(p + k * rows) * C + 4 * q);
+                    gv[k] = *reinterpret_cast<const f32x4*>(dyb + (size_t)(p + k * rows) * C + 4 * q);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 xh = (xv[k] - mu) * rs;
+                    f32x4 gg = gv[k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gg[e] *= act_grad(xh[e] * ga[e] + be[e], act);
+                    s1 += gg;
+                    s2 += gg * xh;
+                }
+            }
+            for (; p < p1; p += rows) {
                 const f32x4 xh = (*reinterpret_cast<const f32x4*>(xb + (size_t)p * C + 4 * q) - mu) * rs;
                 f32x4 gg = *reinterpret_cast<const f32x4*>(dyb + (size_t)p * C + 4 * q);
 #pragma unroll
@@ -145,7 +175,26 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     if (!BWD) {
         const f32x4 A = *reinterpret_cast<const f32x4*>(&sm[4 * q]), B = *reinterpret_cast<const f32x4*>(&sm[C + 4 * q]);
         const f32x4 M = *reinterpret_cast<const f32x4*>(&sm[2 * C + 4 * q]);
-        for (int p = p0 + row; p < p1; p += rows) {
+        int p = p0 + row;
+        for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent pixels per trip: 4-8 loads in flight per thread
+            f32x4 v[4], r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
+                v[k] = *reinterpret_cast<const f32x4*>(x + o);
+                if (residual) r[k] = *reinterpret_cast<const f32x4*>(residual + o);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
+                f32x4 w = (v[k] - M) * A + B;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = apply_act(w[e], act);
+                if (residual) w += r[k];
+                *reinterpret_cast<f32x4*>(out + o) = w;
+            }
+        }
+        for (; p < p1; p += rows) {
             const size_t o = base + (size_t)p * C + 4 * q;
             f32x4 v = (*reinterpret_cast<const f32x4*>(x + o) - M) * A + B;
 #pragma unroll
@@ -158,7 +207,26 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         const f32x4 m1 = *reinterpret_cast<const f32x4*>(&sm[2 * C + 4 * q]), m2 = *reinterpret_cast<const f32x4*>(&sm[3 * C + 4 * q]);
         f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
         if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
-        for (int p = p0 + row; p < p1; p += rows) {
+        int p = p0 + row;
+        for (; p + 3 * rows < p1; p += 4 * rows) {
+            f32x4 xv[4], gv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
+                xv[k] = *reinterpret_cast<const f32x4*>(x + o);
+                gv[k] = *reinterpret_cast<const f32x4*>(dy + o);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
+                const f32x4 xh = (xv[k] - mu) * rs;
+                f32x4 gg = gv[k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gg[e] *= act_grad(xh[e] * ga[e] + be[e], act);
+                *reinterpret_cast<f32x4*>(out + o) = rs * ga * (gg - m1 - xh * m2);
+            }
+        }
+        for (; p < p1; p += rows) {
             const size_t o = base + (size_t)p * C + 4 * q;
             const f32x4 xh = (*reinterpret_cast<const f32x4*>(x + o) - mu) * rs;
             f32x4 gg = *reinterpret_cast<const f32x4*>(dy + o);
