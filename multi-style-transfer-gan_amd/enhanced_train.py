@@ -125,11 +125,12 @@ class EnhancedCycleGAN:
     # Everything that runs through G_AB's and D_A's weights is enqueued on one side stream, everything through G_BA's and
     # D_B's on another: the two halves of a CycleGAN step are independent except where one generator's output feeds the other
     # network, and a step is ~1400 mostly small launches whose drain / fill gaps and tails then overlap (measured: both
-    # generators' forward+backward 35.9 -> 31.6 ms).  Autograd runs every backward node on the stream of its forward, so
-    # the assignment holds for the backward too; each parameter's gradient is only ever touched from one stream.
+    # generators' forward+backward 35.9 -> 31.6 ms; whole step 64.9 -> 54.9 ms).  Autograd runs every backward node on the
+    # stream of its forward, so the assignment holds for the backward too; each parameter's gradient is only ever touched
+    # from one stream.
     def _side_streams(self):
         if getattr(self, "_streams", None) is None:
-            self._streams = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+            self._streams = tuple(torch.cuda.Stream(device=self.device) for _ in range(4))
         return self._streams
 
     def _train_step_async(self, real_A, real_B):
@@ -137,20 +138,25 @@ class EnhancedCycleGAN:
         nb = real_A.shape[0]
         main = torch.cuda.current_stream(self.device)
         two = self.two_streams and not ops.KernelTimer.enabled  # per-launch timing wants one stream
-        sA, sB = self._side_streams() if two else (main, main)
+        # sA: G_AB and D_A, sB: G_BA and D_B.  MSTG_STREAMS=4 gives the discriminators streams of their own (sC, sD); measured
+        # slower on MI355X (1116 vs 1154 images/s): four queues contend more than the extra overlap returns.
+        sA, sB, sC, sD = self._side_streams() if two else (main, main, main, main)
+        if os.environ.get("MSTG_STREAMS", "1") != "4":
+            sC, sD = sA, sB
+        side = (sA, sB, sC, sD)
 
         def fork():
             if two:
-                sA.wait_stream(main)
-                sB.wait_stream(main)
+                for st in side:
+                    st.wait_stream(main)
 
         def join(*tensors):
-            """main waits for both side streams; `tensors` were allocated there and are used elsewhere from now on"""
+            """main waits for the side streams; `tensors` were allocated there and are used elsewhere from now on"""
             if two:
-                main.wait_stream(sA)
-                main.wait_stream(sB)
+                for st in side:
+                    main.wait_stream(st)
                 for t in tensors:
-                    for st in (main, sA, sB):
+                    for st in (main,) + side:
                         t.record_stream(st)
 
         def on(st):
@@ -179,11 +185,11 @@ class EnhancedCycleGAN:
         # ---- discriminator update (reference :67-85)
         self.d_optimizer.zero_grad(set_to_none=True)
         fork()
-        with on(sA):
+        with on(sC):
             real_A_score, _ = D_A(real_A)
             fake_A_score, _ = D_A(fake_A.detach())
             dA_real, dA_fake = ops.mse_to_const(real_A_score, 1.0), ops.mse_to_const(fake_A_score, 0.0)
-        with on(sB):
+        with on(sD):
             real_B_score, _ = D_B(real_B)
             fake_B_score, _ = D_B(fake_B.detach())
             dB_real, dB_fake = ops.mse_to_const(real_B_score, 1.0), ops.mse_to_const(fake_B_score, 0.0)
@@ -212,19 +218,21 @@ class EnhancedCycleGAN:
             # forward performs, so the call count per D is kept at the reference's 5 per step, in the reference's order.
             fork()
             with on(sA):
-                fake_A_score, fake_A_struct = D_A(fake_A)
-                gA = ops.mse_to_const(fake_A_score, 1.0)
                 recon_B = G_AB(fake_A)
                 cB = ops.l1_loss(recon_B, real_B)
+            with on(sB):
+                recon_A = G_BA(fake_B)
+                cA = ops.l1_loss(recon_A, real_A)
+            with on(sC):
+                fake_A_score, fake_A_struct = D_A(fake_A)
+                gA = ops.mse_to_const(fake_A_score, 1.0)
                 with torch.no_grad():
                     _, real_A_struct = D_A(real_A)
                 _, fake_A_struct = D_A(fake_A)
                 sA_l = ops.l1_loss(real_A_struct, fake_A_struct)
-            with on(sB):
+            with on(sD):
                 fake_B_score, fake_B_struct = D_B(fake_B)
                 gB = ops.mse_to_const(fake_B_score, 1.0)
-                recon_A = G_BA(fake_B)
-                cA = ops.l1_loss(recon_A, real_A)
                 with torch.no_grad():
                     _, real_B_struct = D_B(real_B)
                 _, fake_B_struct = D_B(fake_B)
