@@ -161,6 +161,9 @@ def main():
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
         roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"])
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic(sym, args)
+        # per-launch durations are taken with the step on ONE stream (EnhancedCycleGAN drops its two side streams while
+        # ops.KernelTimer is enabled): on two streams launches overlap and a launch's event-to-event time includes its neighbour
+        roofline["measured"] = "instrumented step on one stream (MSTG_STREAMS=0 equivalent); timed region runs on two"
         roofline.update({"kernel": sym, "launches_per_step": r["launches"], "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                          "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2)})
 

@@ -11,6 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $out/${tag}_prof $out/${tag}_pmc_fetch $out/${tag}_pmc_write
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_prof.log 2>&1 || exit 2
 find $out/${tag}_prof -name "*kernel_trace.csv" -delete
+# the same command on one stream: per-kernel durations comparable with bench.py's roofline (measured on one stream)
+rm -rf $out/${tag}_prof1
+MSTG_STREAMS=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof1 -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/${tag}_prof1.log 2>&1 || exit 2
+find $out/${tag}_prof1 -name "*kernel_trace.csv" -delete
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/${tag}_pmc_fetch -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $out/${tag}_pmc_fetch.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/${tag}_pmc_write -o run -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $out/${tag}_pmc_write.log 2>&1 || exit 4
 cd $GRAFT_REPO_ROOT
