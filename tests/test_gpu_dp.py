@@ -14,8 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_two_rank_train_step_on_one_gpu():
-    if not torch.cuda.is_available():
+    # device_count() does not initialise the GPU; a child may only be exec'ed from a process that has not touched it yet
+    # (this module sorts first among the gpu-marked ones, so in the plain `pytest -m gpu` order that holds)
+    if torch.cuda.device_count() < 1:
         pytest.skip("no GPU")
+    if torch.cuda.is_initialized():
+        pytest.skip("this process has already initialised the GPU: launching ranks from it is not allowed on the pool")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "tools", "rehearse_dp_gpu.py")]
