@@ -52,6 +52,10 @@ struct WGradArgs {
 };
 
 constexpr int WT_H = 8, WT_W = 16;
+#ifndef WG_WAVES
+#define WG_WAVES 4  // waves per SIMD the register allocation must allow (4 -> <= 128 VGPRs): measured +10-15 % on the
+                    // small-channel layers (7x7, 16<->32 4x4); the 16-tap variant with 64-channel operands is faster left alone
+#endif
 
 // Stage one tile's gathered patch and grid-tensor tile into LDS (shared by both kernels).  The aligned NHWC cases and the
 // <= 4-channel cases go through the batched helpers of common.h; the rest (odd channel counts, wide NCHW) keeps simple loops.
@@ -148,7 +152,7 @@ __device__ __forceinline__ void wgrad_stage(const WGradArgs& a, float* patch, fl
 
 // TG  : accumulator fragments (taps) per workgroup z-slice;  NFH : 16-wide grid-channel fragments per workgroup
 template <int TG, int NFH>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
+__global__ __launch_bounds__(256, (TG >= 16 ? 2 : WG_WAVES)) void wgrad_kernel(const WGradArgs a) {
     constexpr int BN = 16 * NFH, BNP = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                        // [PH][PW][ckp]
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WGradArgs a) {
 // TH (4 or 8) is the tile height: stride-2 patches are large, a 4-row tile keeps three workgroups per CU.
 // =====================================================================================================================
 template <int UW>
-__global__ __launch_bounds__(256) void wgrad_ts_kernel(const WGradArgs a, const int TH, const int NFHT) {
+__global__ __launch_bounds__(256, WG_WAVES) void wgrad_ts_kernel(const WGradArgs a, const int TH, const int NFHT) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ckp = a.ckp, s = a.stride, mode = a.mode;
     const int BNP = 16 * NFHT + 4;
