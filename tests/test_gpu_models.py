@@ -362,3 +362,26 @@ def test_train_step_with_style_loss_vs_oracle():
         mine[(idx >= len(all_names) // 2, n)] = ours[off:off + p.numel()].view(p.shape)
     keys = [(False, k) for k in names] + [(True, k) for k in names]
     check_grads("train_step + style loss g-gradients", [k for _, k in keys], [mine[k] for k in keys], list(grads))
+
+
+def test_train_step_schedules_are_bit_identical():
+    """Two side streams vs one, gradient checkpointing on vs off: same losses and same parameters, bit for bit, after three
+    steps (every reduction has a fixed order; each parameter's gradient is only ever written from one stream)."""
+    import enhanced_train
+
+    def run(ckpt, streams):
+        torch.manual_seed(3)
+        m = enhanced_train.EnhancedCycleGAN(channels=16, num_transformer_blocks=0, device=torch.device(DEV), gradient_checkpointing=ckpt)
+        m.two_streams = streams
+        g = torch.Generator().manual_seed(5)
+        a = (torch.rand((4, 3, 64, 64), generator=g) * 2 - 1).to(DEV)
+        b = (torch.rand((4, 3, 64, 64), generator=g) * 2 - 1).to(DEV)
+        out = [m.train_step(a, b) for _ in range(3)]
+        return out, m.g_optimizer.flat.clone(), m.d_optimizer.flat.clone()
+
+    ref = run(False, False)
+    for ckpt, streams in ((False, True), (True, False), (True, True)):
+        o = run(ckpt, streams)
+        for i in range(3):
+            assert o[0][i] == ref[0][i], (ckpt, streams, i, o[0][i], ref[0][i])
+        assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (ckpt, streams)
