@@ -90,7 +90,11 @@ def pmc_traffic(sym: str, args):
 def main():
     args = parse()
     from mstg_hip import dp, ops
-    local = dp.init_from_env("nccl")
+    # MSTG_BENCH_REHEARSE=1: rehearsal of the N > 1 flow on a one-GPU box -- gloo instead of RCCL, every rank on cuda:0
+    rehearse = os.environ.get("MSTG_BENCH_REHEARSE", "0") == "1"
+    local = dp.init_from_env("gloo" if rehearse else "nccl")
+    if rehearse:
+        local = 0
     world = dp.world_size()
     if world != args.gpus:
         if dp.rank() == 0:
@@ -133,11 +137,13 @@ def main():
     value = 2.0 * args.batch * world / (dt / args.steps)
 
     roofline = None
-    if not args.no_roofline and dp.rank() == 0:
+    if not args.no_roofline:
+        # EVERY rank runs the instrumented step (it contains the two gradient all-reduces); only rank 0 reports
         ops.KernelTimer.enabled, ops.KernelTimer.records = True, []
         model.train_step_async(real_A, real_B)
         torch.cuda.synchronize()
         ops.KernelTimer.enabled = False
+    if not args.no_roofline and dp.rank() == 0:
         table = ops.KernelTimer.summary()
         total_ms = sum(r["ms"] for r in table.values())
         if args.kernel_table:
