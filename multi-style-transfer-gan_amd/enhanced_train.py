@@ -220,6 +220,15 @@ class EnhancedCycleGAN:
             with on(sA):
                 recon_B = G_AB(fake_A)
                 cB = ops.l1_loss(recon_B, real_B)
+            # enqueue order: stream A gets its large reconstruction first and its discriminator's small launches second,
+            # stream B the other way round, so that small work overlaps large work rather than small with small
+            with on(sD):
+                fake_B_score, fake_B_struct = D_B(fake_B)
+                gB = ops.mse_to_const(fake_B_score, 1.0)
+                with torch.no_grad():
+                    _, real_B_struct = D_B(real_B)
+                _, fake_B_struct = D_B(fake_B)
+                sB_l = ops.l1_loss(real_B_struct, fake_B_struct)
             with on(sB):
                 recon_A = G_BA(fake_B)
                 cA = ops.l1_loss(recon_A, real_A)
@@ -230,13 +239,6 @@ class EnhancedCycleGAN:
                     _, real_A_struct = D_A(real_A)
                 _, fake_A_struct = D_A(fake_A)
                 sA_l = ops.l1_loss(real_A_struct, fake_A_struct)
-            with on(sD):
-                fake_B_score, fake_B_struct = D_B(fake_B)
-                gB = ops.mse_to_const(fake_B_score, 1.0)
-                with torch.no_grad():
-                    _, real_B_struct = D_B(real_B)
-                _, fake_B_struct = D_B(fake_B)
-                sB_l = ops.l1_loss(real_B_struct, fake_B_struct)
             join(gA, gB, cA, cB, sA_l, sB_l)
             g_loss = gA + gB
             cycle_loss = (cA + cB) * self.lambda_cycle
