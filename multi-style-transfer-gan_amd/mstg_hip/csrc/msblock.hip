@@ -12,6 +12,7 @@
 //   units (no cross-wave reduction).  Per-workgroup partial slabs are reduced in a fixed order by a second kernel, which also
 //   scatters the accumulators into the four PyTorch-layout weight gradients and the four bias gradients.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstg {
 
@@ -350,6 +351,97 @@ __global__ __launch_bounds__(256) void ms_dgrad_kernel(const float* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tap-packed weight gradient (CH = 16 and 32).  In the unit kernel above a ring tap uses only the CH/4 columns of its branch:
+// at CH = 16 three quarters of every ring MFMA are wasted.  Writing
+//     dW[tap][ci][co] = sum_p x[p + tap][ci] dy[p][co] = sum_p' x[p'][ci] dy[p' - tap][co]
+// moves the tap shift from x to dy, and the MFMA's B operand is a per-lane gather: column n = (tap slot s, co) reads
+// dy[p' - tap_s][co of the branch].  One MFMA then covers 16/(CH/4) taps of a branch: 7 MFMAs per pixel group instead of 25
+// at CH = 16, 14 instead of 26 at CH = 32.  x needs no halo here; the dy patch carries it (halo 4).
+// Units: u < NFH: centre tap, dy fragment u (all branches at tap 0);  then branch j = 1..3, TPU = 16 / C4 ring taps each.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CH>
+struct MsPk {
+    static constexpr int NFH = CH / 16, C4 = CH / 4, TPU = 16 / C4, UPB = 8 / TPU, U = NFH + 3 * UPB, UW = (U + 3) / 4;
+    static constexpr int NG = CH / 16, PSTRIDE = NG * U * 256 + CH, LDY = CH + 4;
+};
+
+template <int CH>
+__global__ __launch_bounds__(256) void wgrad_msp_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ partial, int N, int H, int W, int tiles_x, int tiles_y,
+                                                        int ntiles) {
+    typedef MsPk<CH> G;
+    constexpr int UW = G::UW, U = G::U, LDY = G::LDY;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                             // [TH*16][CKP]   16 input channels of this chunk, no halo
+    float* dyp = smem + MS_TH * 16 * MS_CKP;      // [PH][PW][LDY]  all CH output-gradient channels, halo 4
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int gchunk = blockIdx.y, g0 = 16 * gchunk;
+
+    f32x4 acc[UW];
+    int boff[UW];  // per-lane offset of this unit's B element inside the dy patch, relative to the pixel (r + 4, c + 4)
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        const int u = min(wave + 4 * k, U - 1);
+        int off;
+        if (u < G::NFH) {
+            off = 16 * u + i;  // centre tap: dy channel 16 u + i
+        } else {
+            const int j = 1 + (u - G::NFH) / G::UPB, m = (u - G::NFH) % G::UPB;  // branch, unit inside the ring
+            const int sidx = i / G::C4, co = i % G::C4, i8 = m * G::TPU + sidx, t9 = i8 < 4 ? i8 : i8 + 1, d = 1 << (j - 1);
+            const int oy = (t9 / 3 - 1) * d, ox = (t9 % 3 - 1) * d;
+            off = (-oy * MS_PW - ox) * LDY + j * G::C4 + co;  // dy[p' - tap][branch channel]
+        }
+        boff[k] = off;
+        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int nu = (U - wave + 3) / 4;
+
+    const bool do_bias = gchunk == 0;
+    float bsum = 0.f;
+    const unsigned m_pw = magic_u32(MS_PW), m_nq = magic_u32(CH / 4);
+    const size_t plane = (size_t)H * W;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        __syncthreads();
+        stage_window(x + (size_t)n * plane * CH + g0, xs, MS_TH, 16, 4, 0x10000000u, 0x40000000u, ty0 * MS_TH, tx0 * 16, H, W, CH, 4, MS_CKP,
+                     tid);
+        stage_window(dy + (size_t)n * plane * CH, dyp, MS_PH, MS_PW, CH / 4, m_pw, m_nq, ty0 * MS_TH - 4, tx0 * 16 - 4, H, W, CH, CH / 4, LDY,
+                     tid);
+        __syncthreads();
+        if (do_bias && tid < CH) {
+            for (int r = 0; r < MS_TH; ++r)
+#pragma unroll 8
+                for (int c = 0; c < 16; ++c) bsum += dyp[((r + 4) * MS_PW + c + 4) * LDY + tid];
+        }
+#pragma unroll 1
+        for (int r = 0; r < MS_TH; ++r) {
+#pragma unroll 2
+            for (int xs4 = 0; xs4 < 4; ++xs4) {
+                const int c = 4 * xs4 + g;  // this lane's k-slot pixel column
+                const float af = xs[(r * 16 + c) * MS_CKP + i];
+                const int bbase = ((r + 4) * MS_PW + c + 4) * LDY;
+                float bf[UW];
+#pragma unroll
+                for (int k = 0; k < UW; ++k) bf[k] = dyp[bbase + boff[k]];
+#pragma unroll
+                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af, bf[k], acc[k]);
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * G::PSTRIDE;
+    if (do_bias && tid < CH) out[G::NG * U * 256 + tid] = bsum;
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        if (k >= nu) continue;
+        const int u = wave + 4 * k;
+        float* o = out + ((size_t)gchunk * U + u) * 256;  // [m = input channel 4g + e][n = i]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(4 * g + e) * 16 + i] = acc[k][e];
+    }
+}
+
 struct MsGradPtrs {
     float* dw[4];
     float* db[4];
@@ -395,8 +487,49 @@ __global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __res
 }
 
 template <int CH>
+__global__ __launch_bounds__(256) void wgrad_msp_reduce_kernel(const float* __restrict__ partial, MsGradPtrs out, int S, int accumulate) {
+    typedef MsPk<CH> G;
+    constexpr int NACC = G::NG * G::U * 256, PSTRIDE = G::PSTRIDE, C4 = G::C4;
+    __shared__ float sh[16][17];
+    const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + e;
+    float sum = 0.f;
+    if (idx < PSTRIDE)
+        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    sh[row][e] = sum;
+    __syncthreads();
+    if (row != 0 || idx >= PSTRIDE) return;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r += sh[k][e];
+    float* o;
+    if (idx >= NACC) {
+        const int co = idx - NACC;
+        o = &out.db[co / C4][co % C4];
+    } else {
+        const int n = idx & 15, m = (idx >> 4) & 15, u = (idx >> 8) % G::U, gch = idx / (G::U * 256);
+        const int ci = 16 * gch + m;
+        if (u < G::NFH) {
+            const int co = 16 * u + n, j = co / C4, cj = co % C4;
+            o = j == 0 ? &out.dw[0][cj * CH + ci] : &out.dw[j][(cj * CH + ci) * 9 + 4];
+        } else {
+            const int j = 1 + (u - G::NFH) / G::UPB, mm = (u - G::NFH) % G::UPB;
+            const int sidx = n / C4, co = n % C4, i8 = mm * G::TPU + sidx, t9 = i8 < 4 ? i8 : i8 + 1;
+            o = &out.dw[j][(co * CH + ci) * 9 + t9];
+        }
+    }
+    *o = accumulate ? *o + r : r;
+}
+
+template <int CH>
+static bool ms_wgrad_packed() {
+    const char* e = getenv("MSTG_MS_WGRAD_PACKED");
+    return CH <= 32 && !(e && e[0] == '0');
+}
+
+template <int CH>
 static size_t ms_wgrad_plan(int N, int H, int W, int& S, int& tiles_x, int& tiles_y, int& ntiles) {
-    constexpr int NFH = CH / 16, U = NFH + 24, NG = CH / 16, PSTRIDE = NG * U * 256 + CH;
+    constexpr int NFH = CH / 16, U = NFH + 24, NG = CH / 16, PSTRIDE = NG * U * 256 + CH;  // the unit layout is the larger one
     tiles_x = cdiv(W, 16);
     tiles_y = cdiv(H, MS_TH);
     ntiles = N * tiles_x * tiles_y;
@@ -420,6 +553,22 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
                                            160 * 1024);
         if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad_ms)");
         attr_set = true;
+    }
+    if (ms_wgrad_packed<CH>()) {
+        typedef MsPk<CH> P;
+        const size_t ldsp = (size_t)(MS_TH * 16 * MS_CKP + MS_PH * MS_PW * P::LDY) * sizeof(float);
+        static bool attr_set_p = false;
+        if (!attr_set_p) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_msp_kernel<CH>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad_msp)");
+            attr_set_p = true;
+        }
+        hipLaunchKernelGGL((wgrad_msp_kernel<CH>), dim3(S, NG, 1), dim3(256), ldsp, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
+        MSTG_CHECK_LAUNCH("wgrad_msp_kernel");
+        hipLaunchKernelGGL((wgrad_msp_reduce_kernel<CH>), dim3(cdiv(P::PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S, accumulate);
+        MSTG_CHECK_LAUNCH("wgrad_msp_reduce_kernel");
+        return MSTG_OK;
     }
     hipLaunchKernelGGL((wgrad_ms_kernel<CH>), dim3(S, NG, 1), dim3(256), lds, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
     MSTG_CHECK_LAUNCH("wgrad_ms_kernel");

@@ -316,7 +316,8 @@ class MSBranchesFn(torch.autograd.Function):
             slots = [_grad_slot(p) for p in ctx.prefs]
             direct = all(t is not None for t in slots)
             outs = slots if direct else grads
-            _timed(f"wgrad_ms_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
+            sym = "wgrad_msp_kernel" if ch <= 32 and os.environ.get("MSTG_MS_WGRAD_PACKED", "1") != "0" else "wgrad_ms_kernel"
+            _timed(f"{sym}<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
                    lambda: _lib.check(lib.mstg_msblock_wgrad(_p(x), _p(dy), *[_p(t) for t in outs], int(direct), N, H, W, ch, _p(wsb),
                                                              wsb.numel() * 4, _stream()), "mstg_msblock_wgrad"),
                    f"ms-wgrad N{N} {H}x{W} ch{ch}")
