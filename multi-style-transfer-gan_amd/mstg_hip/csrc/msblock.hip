@@ -371,15 +371,15 @@ __global__ __launch_bounds__(256) void wgrad_msp_kernel(const float* __restrict_
                                                         float* __restrict__ partial, int N, int H, int W, int tiles_x, int tiles_y,
                                                         int ntiles) {
     typedef MsPk<CH> G;
-    constexpr int UW = G::UW, U = G::U, LDY = G::LDY;
+    constexpr int UW = G::UW, U = G::U, LDY = G::LDY, MG = G::NG, LDX = CH + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                             // [TH*16][CKP]   16 input channels of this chunk, no halo
-    float* dyp = smem + MS_TH * 16 * MS_CKP;      // [PH][PW][LDY]  all CH output-gradient channels, halo 4
+    float* xs = smem;                          // [TH*16][LDX]   ALL input channels (one workgroup owns every 16-channel chunk: the
+                                               //                dy patch, the expensive operand, is staged once, not once per chunk)
+    float* dyp = smem + MS_TH * 16 * LDX;      // [PH][PW][LDY]  all CH output-gradient channels, halo 4
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-    const int gchunk = blockIdx.y, g0 = 16 * gchunk;
 
-    f32x4 acc[UW];
+    f32x4 acc[UW][MG];
     int boff[UW];  // per-lane offset of this unit's B element inside the dy patch, relative to the pixel (r + 4, c + 4)
 #pragma unroll
     for (int k = 0; k < UW; ++k) {
@@ -394,23 +394,22 @@ __global__ __launch_bounds__(256) void wgrad_msp_kernel(const float* __restrict_
             off = (-oy * MS_PW - ox) * LDY + j * G::C4 + co;  // dy[p' - tap][branch channel]
         }
         boff[k] = off;
-        acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mf = 0; mf < MG; ++mf) acc[k][mf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nu = (U - wave + 3) / 4;
 
-    const bool do_bias = gchunk == 0;
     float bsum = 0.f;
     const unsigned m_pw = magic_u32(MS_PW), m_nq = magic_u32(CH / 4);
     const size_t plane = (size_t)H * W;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         __syncthreads();
-        stage_window(x + (size_t)n * plane * CH + g0, xs, MS_TH, 16, 4, 0x10000000u, 0x40000000u, ty0 * MS_TH, tx0 * 16, H, W, CH, 4, MS_CKP,
-                     tid);
+        stage_window(x + (size_t)n * plane * CH, xs, MS_TH, 16, CH / 4, 0x10000000u, m_nq, ty0 * MS_TH, tx0 * 16, H, W, CH, CH / 4, LDX, tid);
         stage_window(dy + (size_t)n * plane * CH, dyp, MS_PH, MS_PW, CH / 4, m_pw, m_nq, ty0 * MS_TH - 4, tx0 * 16 - 4, H, W, CH, CH / 4, LDY,
                      tid);
         __syncthreads();
-        if (do_bias && tid < CH) {
+        if (tid < CH) {
             for (int r = 0; r < MS_TH; ++r)
 #pragma unroll 8
                 for (int c = 0; c < 16; ++c) bsum += dyp[((r + 4) * MS_PW + c + 4) * LDY + tid];
@@ -420,25 +419,31 @@ __global__ __launch_bounds__(256) void wgrad_msp_kernel(const float* __restrict_
 #pragma unroll 2
             for (int xs4 = 0; xs4 < 4; ++xs4) {
                 const int c = 4 * xs4 + g;  // this lane's k-slot pixel column
-                const float af = xs[(r * 16 + c) * MS_CKP + i];
+                float af[MG], bf[UW];
+#pragma unroll
+                for (int mf = 0; mf < MG; ++mf) af[mf] = xs[(r * 16 + c) * LDX + 16 * mf + i];
                 const int bbase = ((r + 4) * MS_PW + c + 4) * LDY;
-                float bf[UW];
 #pragma unroll
                 for (int k = 0; k < UW; ++k) bf[k] = dyp[bbase + boff[k]];
 #pragma unroll
-                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af, bf[k], acc[k]);
+                for (int k = 0; k < UW; ++k)
+#pragma unroll
+                    for (int mf = 0; mf < MG; ++mf) acc[k][mf] = mfma16(af[mf], bf[k], acc[k][mf]);
             }
         }
     }
     float* out = partial + (size_t)blockIdx.x * G::PSTRIDE;
-    if (do_bias && tid < CH) out[G::NG * U * 256 + tid] = bsum;
+    if (tid < CH) out[G::NG * U * 256 + tid] = bsum;
 #pragma unroll
     for (int k = 0; k < UW; ++k) {
         if (k >= nu) continue;
         const int u = wave + 4 * k;
-        float* o = out + ((size_t)gchunk * U + u) * 256;  // [m = input channel 4g + e][n = i]
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[(4 * g + e) * 16 + i] = acc[k][e];
+        for (int mf = 0; mf < MG; ++mf) {
+            float* o = out + ((size_t)mf * U + u) * 256;  // [chunk mf][unit][m = input channel 4g + e][n = i]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(4 * g + e) * 16 + i] = acc[k][mf][e];
+        }
     }
 }
 
@@ -536,7 +541,13 @@ static size_t ms_wgrad_plan(int N, int H, int W, int& S, int& tiles_x, int& tile
     S = 768 / NG;
     if (S > ntiles) S = ntiles;
     if (S < 1) S = 1;
-    return (size_t)S * PSTRIDE * sizeof(float);
+    size_t need = (size_t)S * PSTRIDE;
+    if (CH <= 32) {  // the tap-packed kernel: S * NG workgroups, smaller slabs
+        const size_t sp = (size_t)S * NG > (size_t)ntiles ? (size_t)ntiles : (size_t)S * NG;
+        const size_t np = sp * MsPk<(CH <= 32 ? CH : 16)>::PSTRIDE;
+        if (np > need) need = np;
+    }
+    return need * sizeof(float);
 }
 
 template <int CH>
@@ -556,7 +567,7 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
     }
     if (ms_wgrad_packed<CH>()) {
         typedef MsPk<CH> P;
-        const size_t ldsp = (size_t)(MS_TH * 16 * MS_CKP + MS_PH * MS_PW * P::LDY) * sizeof(float);
+        const size_t ldsp = (size_t)(MS_TH * 16 * (CH + 4) + MS_PH * MS_PW * P::LDY) * sizeof(float);
         static bool attr_set_p = false;
         if (!attr_set_p) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_msp_kernel<CH>),
@@ -564,9 +575,10 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
             if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(wgrad_msp)");
             attr_set_p = true;
         }
-        hipLaunchKernelGGL((wgrad_msp_kernel<CH>), dim3(S, NG, 1), dim3(256), ldsp, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
+        const int Sp = S * NG > ntiles ? ntiles : S * NG;  // one workgroup covers every input-channel chunk: keep the workgroup count
+        hipLaunchKernelGGL((wgrad_msp_kernel<CH>), dim3(Sp, 1, 1), dim3(256), ldsp, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
         MSTG_CHECK_LAUNCH("wgrad_msp_kernel");
-        hipLaunchKernelGGL((wgrad_msp_reduce_kernel<CH>), dim3(cdiv(P::PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S, accumulate);
+        hipLaunchKernelGGL((wgrad_msp_reduce_kernel<CH>), dim3(cdiv(P::PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, Sp, accumulate);
         MSTG_CHECK_LAUNCH("wgrad_msp_reduce_kernel");
         return MSTG_OK;
     }
