@@ -266,7 +266,8 @@ class MSBranchesFn(torch.autograd.Function):
             wb_ptrs = []
             for j in range(4):
                 wb_ptrs += [_p(ws[j]), _p(bs[j])]
-            _timed(f"ms_fwd_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
+            fwd4 = ch == 16 and H >= 16 and os.environ.get("MSTG_MS_FWD4", "1") != "0"
+            _timed("ms_fwd4_kernel" if fwd4 else f"ms_fwd_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
                    lambda: _lib.check(lib.mstg_msblock_fwd(_p(x), *wb_ptrs, _p(y), N, H, W, ch, _p(wsb), wsb.numel() * 4, _stream()),
                                       "mstg_msblock_fwd"), f"ms-fwd N{N} {H}x{W} ch{ch}")
         else:
