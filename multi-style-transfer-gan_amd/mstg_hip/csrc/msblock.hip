@@ -457,28 +457,34 @@ __global__ __launch_bounds__(256) void wgrad_msp_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int M4_TH = 16, M4_PH = M4_TH + 8;
 
-template <int JB, int T9, int Q>
+// one (branch, tap, channel quad of the current 16-channel chunk): RS row sets (4 output channels each) share the B value
+template <int CH, int JB, int T9, int Q>
 struct Ms4Step {
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float* __restrict__ wl, const float* __restrict__ patch, int pbase,
+    static constexpr int C4 = CH / 4, RS = C4 / 4;
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4][RS], const float* __restrict__ wl, const float* __restrict__ patch, int pbase,
                                                int wbase) {
         constexpr int d = JB == 0 ? 0 : (1 << (JB - 1));
         constexpr int oy = JB == 0 ? 0 : (T9 / 3 - 1) * d, ox = JB == 0 ? 0 : (T9 % 3 - 1) * d;
         constexpr int t = JB == 0 ? 0 : 1 + 9 * (JB - 1) + T9;  // tap slot in the LDS filter
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&wl[wbase + t * 64 + 4 * Q]);
         const f32x4 b = *reinterpret_cast<const f32x4*>(&patch[pbase + (oy * MS_PW + ox) * MS_CKP + 4 * Q]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[JB] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], acc[JB], 0, 0, 0);
+        for (int rs = 0; rs < RS; ++rs) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&wl[wbase + (t * C4 + 4 * rs) * CH + 4 * Q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[JB][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], b[e], acc[JB][rs], 0, 0, 0);
+        }
     }
 };
 
-template <int JB>
+template <int CH, int JB>
 struct Ms4Branch {
-    static __device__ __forceinline__ void run(f32x4 (&acc)[4], const float* wl, const float* patch, int pbase, int wbase) {
-#define M4_TAP(T9)                                              \
-    Ms4Step<JB, T9, 0>::run(acc, wl, patch, pbase, wbase);      \
-    Ms4Step<JB, T9, 1>::run(acc, wl, patch, pbase, wbase);      \
-    Ms4Step<JB, T9, 2>::run(acc, wl, patch, pbase, wbase);      \
-    Ms4Step<JB, T9, 3>::run(acc, wl, patch, pbase, wbase);
+    static constexpr int RS = CH / 16;
+    static __device__ __forceinline__ void run(f32x4 (&acc)[4][RS], const float* wl, const float* patch, int pbase, int wbase) {
+#define M4_TAP(T9)                                                  \
+    Ms4Step<CH, JB, T9, 0>::run(acc, wl, patch, pbase, wbase);      \
+    Ms4Step<CH, JB, T9, 1>::run(acc, wl, patch, pbase, wbase);      \
+    Ms4Step<CH, JB, T9, 2>::run(acc, wl, patch, pbase, wbase);      \
+    Ms4Step<CH, JB, T9, 3>::run(acc, wl, patch, pbase, wbase);
         if (JB == 0) {
             M4_TAP(0)
         } else {
@@ -488,44 +494,54 @@ struct Ms4Branch {
     }
 };
 
+template <int CH>
 __global__ __launch_bounds__(256) void ms_fwd4_kernel(const float* __restrict__ x, MsParamPtrs prm, float* __restrict__ y, int N, int H,
                                                       int W, int tiles_x, int tiles_y) {
-    constexpr int CH = 16, C4 = 4;
+    constexpr int C4 = CH / 4, RS = C4 / 4, NCHK = CH / 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                  // [M4_PH][PW][CKP]
-    float* wl = smem + M4_PH * MS_PW * MS_CKP;            // [28 taps][4 co][16 ci]
+    float* patch = smem;                                  // [M4_PH][PW][CKP]   one 16-channel chunk of x at a time
+    float* wl = smem + M4_PH * MS_PW * MS_CKP;            // [28 taps][C4 co][CH ci]   the whole filter, staged once
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
     const size_t plane = (size_t)H * W;
-    // ---- filter: wl[(t * 4 + co) * 16 + ci] straight from the four PyTorch-layout tensors -----------------------------------
-    for (int e = tid; e < 28 * 64; e += 256) {
-        const int ci = e & 15, co = (e >> 4) & 3, t = e >> 6;
+    // ---- filter: wl[(t * C4 + co) * CH + ci] straight from the four PyTorch-layout tensors ----------------------------------
+    for (int e = tid; e < 28 * C4 * CH; e += 256) {
+        const int ci = e % CH, co = (e / CH) % C4, t = e / (CH * C4);
         float v;
         if (t == 0) v = prm.w[0][co * CH + ci];
         else v = prm.w[1 + (t - 1) / 9][(co * CH + ci) * 9 + (t - 1) % 9];
         wl[e] = v;
     }
-    stage_window(x + (size_t)n * plane * CH, patch, M4_PH, MS_PW, 4, magic_u32(MS_PW), 0x40000000u, ty0 * M4_TH - 4, tx0 * 16 - 4, H, W, CH, 4,
-                 MS_CKP, tid);
-    __syncthreads();
-    // lane (block b, j): pixel row 4*wave + b/4, column 4*(b%4) + j ; supplies the weights of output channel j
+    // lane (block b, j): pixel row 4*wave + b/4, column 4*(b%4) + j ; supplies the weights of output channel 4*rs + j
     const int b = lane >> 2, j = lane & 3;
     const int prow = 4 * wave + (b >> 2), pcol = 4 * (b & 3) + j;
     const int pbase = ((prow + 4) * MS_PW + pcol + 4) * MS_CKP;
-    const int wbase = j * 16;
-    f32x4 acc[4];
+    f32x4 acc[4][RS];
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) acc[jb] = *reinterpret_cast<const f32x4*>(prm.b[jb]);  // bias: register r = channel r of the branch
-    Ms4Branch<0>::run(acc, wl, patch, pbase, wbase);
-    Ms4Branch<1>::run(acc, wl, patch, pbase, wbase);
-    Ms4Branch<2>::run(acc, wl, patch, pbase, wbase);
-    Ms4Branch<3>::run(acc, wl, patch, pbase, wbase);
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int rs = 0; rs < RS; ++rs) acc[jb][rs] = *reinterpret_cast<const f32x4*>(prm.b[jb] + 4 * rs);  // bias: register r = channel 4 rs + r
+    const unsigned m_pw = magic_u32(MS_PW);
+#pragma unroll
+    for (int chunk = 0; chunk < NCHK; ++chunk) {
+        if (chunk) __syncthreads();
+        stage_window(x + (size_t)n * plane * CH + 16 * chunk, patch, M4_PH, MS_PW, 4, m_pw, 0x40000000u, ty0 * M4_TH - 4, tx0 * 16 - 4, H, W,
+                     CH, 4, MS_CKP, tid);
+        __syncthreads();
+        const int wbase = j * CH + 16 * chunk;
+        Ms4Branch<CH, 0>::run(acc, wl, patch, pbase, wbase);
+        Ms4Branch<CH, 1>::run(acc, wl, patch, pbase, wbase);
+        Ms4Branch<CH, 2>::run(acc, wl, patch, pbase, wbase);
+        Ms4Branch<CH, 3>::run(acc, wl, patch, pbase, wbase);
+    }
     const int gy = ty0 * M4_TH + prow, gx = tx0 * 16 + pcol;
     if (gy < H && gx < W) {
         float* p = y + (((size_t)n * H + gy) * W + gx) * CH;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) *reinterpret_cast<f32x4*>(p + C4 * jb) = acc[jb];
+        for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+            for (int rs = 0; rs < RS; ++rs) *reinterpret_cast<f32x4*>(p + C4 * jb + 4 * rs) = acc[jb][rs];
     }
 }
 
@@ -678,17 +694,19 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
         const char* e = getenv("MSTG_MS_FWD4");
         bool aligned = true;
         for (int k = 0; k < 4; ++k) aligned = aligned && (reinterpret_cast<uintptr_t>(prm.b[k]) & 15) == 0;
-        if (CH == 16 && aligned && H >= 16 && !(e && e[0] == '0')) {  // measured 1.6x faster than the 16-row-tile kernel
+        const bool use4 = CH == 16 || (CH == 32 && e && e[0] == '2');
+        if (use4 && aligned && H >= 16 && !(e && e[0] == '0')) {  // measured 1.6x faster than the 16-row-tile kernel at CH = 16
+            constexpr int C4K = (CH <= 32 ? CH : 16);
             const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, M4_TH);
-            const size_t lds = (size_t)(M4_PH * MS_PW * MS_CKP + 28 * 64) * sizeof(float);
+            const size_t lds = (size_t)(M4_PH * MS_PW * MS_CKP + 28 * (C4K / 4) * C4K) * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
-                hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_fwd4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    160 * 1024);
+                hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_fwd4_kernel<C4K>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (er != hipSuccess) return fail_launch(er, "hipFuncSetAttribute(ms_fwd4)");
                 attr4 = true;
             }
-            hipLaunchKernelGGL(ms_fwd4_kernel, dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
+            hipLaunchKernelGGL((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
             MSTG_CHECK_LAUNCH("ms_fwd4_kernel");
             return MSTG_OK;
         }
