@@ -149,22 +149,33 @@ __device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
     float* invn = sm + T::INVN;
     ATT_FSTAMP(2)
     // ---- L2 normalise q and k per pixel over channels (F.normalize: v / max(||v||, 1e-12)) ----------------------
+    // lane = (pixel lane >> 2, channel quarter lane & 3): 16-byte LDS accesses and a reduction that stays inside a quad (two DPP
+    // quad_perm steps) -- the previous (pixel i, quarter g) split needed cross-row ds_bpermute shuffles and scalar LDS traffic
     {
+        constexpr int QW = CP / 4, NV = QW / 4;
+        const int p = lane >> 2, cq = lane & 3;
+        float* qp = &qkv[p * T::LDQ + cq * QW];
+        f32x4 qa[NV], ka[NV];
         float sq = 0.f, sk = 0.f;
-        const int c0 = g * (CP / 4);
-        for (int c = c0; c < c0 + CP / 4; ++c) {
-            const float a = qkv[i * T::LDQ + c], b = qkv[i * T::LDQ + CP + c];
-            sq += a * a;
-            sk += b * b;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            qa[v] = *reinterpret_cast<const f32x4*>(qp + 4 * v);
+            ka[v] = *reinterpret_cast<const f32x4*>(qp + CP + 4 * v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sq = fmaf(qa[v][e], qa[v][e], sq);
+                sk = fmaf(ka[v][e], ka[v][e], sk);
+            }
         }
-        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
-        sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+        sq += dpp_move<0xB1>(sq); sq += dpp_move<0x4E>(sq);
+        sk += dpp_move<0xB1>(sk); sk += dpp_move<0x4E>(sk);
         const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
-        for (int c = c0; c < c0 + CP / 4; ++c) {
-            qkv[i * T::LDQ + c] *= iq;
-            qkv[i * T::LDQ + CP + c] *= ik;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            *reinterpret_cast<f32x4*>(qp + 4 * v) = qa[v] * iq;
+            *reinterpret_cast<f32x4*>(qp + CP + 4 * v) = ka[v] * ik;
         }
-        if (g == 0) { invn[i] = iq; invn[16 + i] = ik; }
+        if (cq == 0) { invn[p] = iq; invn[16 + p] = ik; }
     }
     WAVE_SYNC();
     ATT_FSTAMP(3)
