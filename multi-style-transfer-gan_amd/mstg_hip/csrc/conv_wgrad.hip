@@ -610,7 +610,7 @@ static TsPlan plan_ts(WGradArgs& a) {
     a.PH = (p.TH - 1) * a.stride + (a.KH - 1) * a.dil + 1;
     const int nfh_all = a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16);
     p.NFHT = nfh_all > 4 ? 4 : nfh_all;
-    while (a.Teff * p.NFHT > 32) --p.NFHT;  // at most 8 units per wave (16 would need > 128 VGPRs)
+    while (p.NFHT > 1 && a.Teff * p.NFHT > 32) --p.NFHT;  // at most 8 units per wave (16 would need > 128 VGPRs)
     p.ngroups = cdiv(nfh_all, p.NFHT);
     const int U = a.Teff * p.NFHT;
     p.UW = U <= 16 ? 4 : (U <= 32 ? 8 : 16);
@@ -705,7 +705,7 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     WGradArgs a{};
     if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
     const size_t w_old = plan_wgrad(a).ws_bytes;
-    const size_t w_ts = a.Teff > 1 ? plan_ts(a).ws_bytes : 0;
+    const size_t w_ts = (a.Teff == 16 && a.mode == MODE_PLAIN) ? plan_ts(a).ws_bytes : 0;  // the only shapes the tap-split kernel takes
     const size_t w_11 = wgrad_1x1_ok(a) ? (size_t)wgrad_1x1_splits(a) * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float) : 0;
     size_t w = w_old > w_ts ? w_old : w_ts;
     return w > w_11 ? w : w_11;

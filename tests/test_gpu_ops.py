@@ -197,6 +197,19 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
         report(f"msbranches db{j + 1}", rel_l2(gg[5 + j], gr[5 + j]), 1e-4)
 
 
+@pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
+                                 "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1"])
+def test_kernel_selection_switches_keep_parity(env, monkeypatch):
+    """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
+    k, v = env.split("=")
+    monkeypatch.setenv(k, v)
+    test_conv_channel_slices_and_accumulate(2, 21, 37, 16)
+    test_conv_channel_slices_and_accumulate(1, 32, 32, 32)
+    for case in CONV_CASES:
+        if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4"):
+            test_conv_fwd_bwd(case)
+
+
 NORM_CASES = [(2, 16, 24, 8, 1), (1, 64, 64, 16, 1), (3, 7, 9, 32, 2), (2, 4, 4, 64, 2), (1, 128, 128, 16, 1), (2, 2, 2, 64, 2),
               (2, 16, 16, 4, 0), (1, 32, 32, 128, 1)]
 
