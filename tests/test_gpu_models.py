@@ -385,3 +385,15 @@ def test_train_step_schedules_are_bit_identical():
         for i in range(3):
             assert o[0][i] == ref[0][i], (ckpt, streams, i, o[0][i], ref[0][i])
         assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (ckpt, streams)
+
+
+@pytest.mark.parametrize("env", ["MSTG_ATTN_UNFUSED=1", "MSTG_TORCH_SPECTRAL_NORM=1", "MSTG_STREAMS=4", "MSTG_STREAMS=0", "MSTG_IGEMM=l",
+                                 "MSTG_IGEMM=h", "MSTG_STREAM=1"])
+def test_module_level_switches_keep_parity(env, gold_dir, monkeypatch):
+    """The module-level switches of INTEGRATION.md section 3 (unfused attention, torch's spectral-norm hook, stream counts, conv
+    kernel families) against the same golden vectors as the defaults."""
+    k, v = env.split("=")
+    monkeypatch.setenv(k, v)
+    test_generator_vs_reference_golden(gold_dir, "c16_64x64", False)
+    test_discriminator_vs_reference_golden(gold_dir)
+    test_train_step_vs_reference_golden(gold_dir)
