@@ -102,10 +102,10 @@ struct AttnTiles {
 // load one window of an (N,H,W,ctot) tensor into a [16][ld] LDS tile, `nblk` channel blocks of C -> CP padding
 template <int CP>
 __device__ __forceinline__ void load_window(const float* __restrict__ src, float* tile, int ld, int nblk, int C, int H, int W,
-                                            int n, int wy, int wx, int lane) {
+                                            int n, int wy, int wx, int lane, int nthr = 64) {
     const int qpb = CP / 4;  // float4 slots per block (padded)
     const int ctot = nblk * C;
-    for (int e = lane; e < 16 * nblk * qpb; e += 64) {
+    for (int e = lane; e < 16 * nblk * qpb; e += nthr) {
         const int q = e % qpb, rest = e / qpb;
         const int blk = rest % nblk, p = rest / nblk;
         const int y = 4 * wy + (p >> 2), x = 4 * wx + (p & 3);
@@ -829,12 +829,273 @@ __global__ __launch_bounds__(64) void attn_core_bwd_blk_kernel(const float* __re
     }
 }
 
+// =====================================================================================================================
+// Four waves per window for 64 < C <= 256.  The one-wave kernels above hold 50 KB (C = 128) / 100 KB (C = 256) of LDS per
+// wave, i.e. three waves / one wave per CU, and every MFMA dependency stalls the SIMD.  Here a 256-thread workgroup shares
+// the q^|k^|v, dO and dq^ tiles of ONE window and the four waves take the 16-row blocks of the attention matrix round-robin
+// (each with its own P / dS tile); what sums over the row blocks (dk^, dV) is added across the waves through those tiles
+// at the end.  LDS per workgroup 78 KB / 151 KB -> eight / four waves per CU.
+// =====================================================================================================================
+template <int CP>
+struct Blk4Tiles {
+    static constexpr int NF = CP / 16, LDQ = 3 * CP + 4, LDP = CP + 4;
+    static constexpr int QKV = 0, INVN = 16 * LDQ, RED = INVN + 32, PW = RED + 512, END_FWD = PW + 4 * 16 * LDP;
+    static constexpr int DO = END_FWD, DQ = DO + 16 * LDP, END_BWD = DQ + 16 * LDP;
+};
+
+// F.normalize of q and k in place with 256 threads: thread (pixel t & 15, part t >> 4) owns CP/16 channels of each
+template <int CP>
+__device__ __forceinline__ void blk4_normalise(float* sm, int tid) {
+    typedef Blk4Tiles<CP> T;
+    float* qkv = sm + T::QKV;
+    float* red = sm + T::RED;  // [2][16 parts][16 pixels]
+    const int p = tid & 15, part = tid >> 4, c0 = part * (CP / 16);
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP / 16; ++c) {
+        const float a = qkv[p * T::LDQ + c0 + c], b = qkv[p * T::LDQ + CP + c0 + c];
+        sq = fmaf(a, a, sq);
+        sk = fmaf(b, b, sk);
+    }
+    red[part * 16 + p] = sq;
+    red[256 + part * 16 + p] = sk;
+    __syncthreads();
+    sq = 0.f;
+    sk = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {  // same order in every thread: all parts of a pixel get the identical norm
+        sq += red[k * 16 + p];
+        sk += red[256 + k * 16 + p];
+    }
+    const float iq = 1.f / fmaxf(sqrtf(sq), 1e-12f), ik = 1.f / fmaxf(sqrtf(sk), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < CP / 16; ++c) {
+        qkv[p * T::LDQ + c0 + c] *= iq;
+        qkv[p * T::LDQ + CP + c0 + c] *= ik;
+    }
+    if (part == 0) {
+        sm[T::INVN + p] = iq;
+        sm[T::INVN + 16 + p] = ik;
+    }
+}
+
+// softmaxed rows [16b, 16b + 16) of the attention matrix -> registers and this wave's tile Ps[16][LDP]
+template <int CP>
+__device__ __forceinline__ void blk4_softmax_rows(f32x4 (&s)[1][CP / 16], const float* qkv, float* Ps, int b, int C, int lane) {
+    typedef Blk4Tiles<CP> T;
+    constexpr int NF = T::NF;
+    const int i = lane & 15;
+    tile_zero<1, NF>(s);
+    tile_mma<1, NF>(s, qkv + 16 * b, 1, T::LDQ, qkv + CP, T::LDQ, 1, 16, lane);  // q^_blk^T k^
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            if (16 * nf + i >= C) s[0][nf][r] = -INFINITY;
+            mx = fmaxf(mx, s[0][nf][r]);
+        }
+        mx = row16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+            s[0][nf][r] = __expf(s[0][nf][r] - mx);
+            sum += s[0][nf][r];
+        }
+        sum = row16_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) s[0][nf][r] *= inv;
+    }
+    tile_store<1, NF>(s, Ps, T::LDP, 1, lane);
+}
+
+template <int CP>
+__global__ __launch_bounds__(256) void attn_core_fwd_blk4_kernel(const float* __restrict__ qkv_g, float* __restrict__ o_g, int N, int H,
+                                                                 int W, int C) {
+    typedef Blk4Tiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    float* qkv = sm + T::QKV;
+    float* Ps = sm + T::PW + wave * 16 * T::LDP;
+    const int nrb = (C + 15) / 16;  // row blocks; every wave runs the same number of rounds (block barriers inside)
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        __syncthreads();
+        load_window<CP>(qkv_g, qkv, T::LDQ, 3, C, H, W, n, wy, wx, tid, 256);
+        __syncthreads();
+        blk4_normalise<CP>(sm, tid);
+        __syncthreads();
+        const int y = 4 * wy + (i >> 2), x = 4 * wx + (i & 3);
+        float* dst = o_g + (((size_t)n * H + y) * W + x) * C;
+        for (int b0 = 0; b0 < nrb; b0 += 4) {
+            const int b = b0 + wave;
+            if (b < nrb) {  // wave-private tile: the wave's own program order is all the synchronisation this needs ...
+                f32x4 s[1][NF];
+                blk4_softmax_rows<CP>(s, qkv, Ps, b, C, lane);
+            }
+            __syncthreads();  // ... but LDS visibility between lanes is only guaranteed across a barrier
+            if (b < nrb) {
+                f32x4 o[1][1];  // O^T[c1 in block][p] = sum_c2 P[c1][c2] V[p][c2]
+                tile_zero<1, 1>(o);
+                tile_mma<1, 1>(o, Ps, T::LDP, 1, qkv + 2 * CP, 1, T::LDQ, CP, lane);
+                const int c = 16 * b + 4 * g;
+                if (c < C) *reinterpret_cast<f32x4*>(dst + c) = o[0][0];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int CP>
+__global__ __launch_bounds__(256) void attn_core_bwd_blk4_kernel(const float* __restrict__ qkv_g, const float* __restrict__ do_g,
+                                                                 float* __restrict__ dqkv_g, int N, int H, int W, int C) {
+    typedef Blk4Tiles<CP> T;
+    constexpr int NF = T::NF;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
+    float* qkv = sm + T::QKV;
+    float* invn = sm + T::INVN;
+    float* PW = sm + T::PW;
+    float* Ps = PW + wave * 16 * T::LDP;
+    float* dOs = sm + T::DO;
+    float* dQ = sm + T::DQ;  // raw dq^ [16][LDP]; wave w fills the columns of its row blocks
+    const int nrb = (C + 15) / 16;
+    for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
+        const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        __syncthreads();
+        load_window<CP>(qkv_g, qkv, T::LDQ, 3, C, H, W, n, wy, wx, tid, 256);
+        load_window<CP>(do_g, dOs, T::LDP, 1, C, H, W, n, wy, wx, tid, 256);
+        __syncthreads();
+        blk4_normalise<CP>(sm, tid);
+        __syncthreads();
+        f32x4 dv[1][NF], dk[1][NF];  // this wave's share of the sums over row blocks: rows = pixels, columns = c2
+        tile_zero<1, NF>(dv);
+        tile_zero<1, NF>(dk);
+        for (int b0 = 0; b0 < nrb; b0 += 4) {
+            const int b = b0 + wave;
+            const bool on = b < nrb;
+            f32x4 s[1][NF], ds[1][NF];
+            if (on) blk4_softmax_rows<CP>(s, qkv, Ps, b, C, lane);  // P rows of this block -> Ps
+            __syncthreads();
+            if (on) {
+                tile_zero<1, NF>(ds);  // dP[c1 blk][c2] = sum_p dO[p][c1] V[p][c2]
+                tile_mma<1, NF>(ds, dOs + 16 * b, 1, T::LDP, qkv + 2 * CP, T::LDQ, 1, 16, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) dot += s[0][nf][r] * ds[0][nf][r];
+                    dot = row16_sum(dot);
+#pragma unroll
+                    for (int nf = 0; nf < NF; ++nf) ds[0][nf][r] = s[0][nf][r] * (ds[0][nf][r] - dot);
+                }
+                // dV[p][c2] += sum_{c1 in blk} dO[p][c1] P[c1][c2]   (P still in Ps)
+                tile_mma<1, NF>(dv, dOs + 16 * b, T::LDP, 1, Ps, T::LDP, 1, 16, lane);
+            }
+            __syncthreads();
+            if (on) tile_store<1, NF>(ds, Ps, T::LDP, 1, lane);  // Ps <- dS block
+            __syncthreads();
+            if (on) {
+                // dq^[p][c1 in blk] = sum_c2 dS[c1][c2] k^[p][c2]
+                f32x4 d[1][1];
+                tile_zero<1, 1>(d);
+                tile_mma<1, 1>(d, qkv + CP, T::LDQ, 1, Ps, 1, T::LDP, CP, lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dQ[(4 * g + r) * T::LDP + 16 * b + i] = d[0][0][r];
+                // dk^[p][c2] += sum_{c1 in blk} dS[c1][c2] q^[p][c1]
+                tile_mma<1, NF>(dk, qkv + 16 * b, T::LDQ, 1, Ps, T::LDP, 1, 16, lane);
+            }
+            __syncthreads();
+        }
+        // ---- combine the four waves: thread (pixel p = tid >> 4, lane-in-row i) owns channels i + 16 j ------------------------------
+        const int p = tid >> 4, pi = tid & 15;
+        const int py = 4 * wy + (p >> 2), px = 4 * wx + (p & 3);
+        float* dst = dqkv_g + (((size_t)n * H + py) * W + px) * 3 * C;
+        tile_store<1, NF>(dk, Ps, T::LDP, 1, lane);
+        __syncthreads();
+        {
+            float v[NF], h[NF], dot = 0.f;
+            // dk = (dk^ - k^ (k^ . dk^)) / ||k||
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int c = 16 * j + pi;
+                v[j] = (PW[p * T::LDP + c] + PW[(16 + p) * T::LDP + c]) + (PW[(32 + p) * T::LDP + c] + PW[(48 + p) * T::LDP + c]);
+                h[j] = qkv[p * T::LDQ + CP + c];
+                dot = fmaf(h[j], v[j], dot);
+            }
+            dot = row16_sum(dot);
+            const float ik = invn[16 + p];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int c = 16 * j + pi;
+                if (c < C) dst[C + c] = (v[j] - h[j] * dot) * ik;
+            }
+            // dq = (dq^ - q^ (q^ . dq^)) / ||q||
+            dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int c = 16 * j + pi;
+                v[j] = c < C ? dQ[p * T::LDP + c] : 0.f;  // columns beyond the last row block were never written
+                h[j] = qkv[p * T::LDQ + c];
+                dot = fmaf(h[j], v[j], dot);
+            }
+            dot = row16_sum(dot);
+            const float iq = invn[p];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int c = 16 * j + pi;
+                if (c < C) dst[c] = (v[j] - h[j] * dot) * iq;
+            }
+        }
+        __syncthreads();
+        tile_store<1, NF>(dv, Ps, T::LDP, 1, lane);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int c = 16 * j + pi;
+            if (c < C)
+                dst[2 * C + c] = (PW[p * T::LDP + c] + PW[(16 + p) * T::LDP + c]) + (PW[(32 + p) * T::LDP + c] + PW[(48 + p) * T::LDP + c]);
+        }
+    }
+}
+
+template <int CP>
+static int launch_attn_blk4(bool bwd, const float* qkv, const float* d_o, float* out, int N, int H, int W, int C, hipStream_t st) {
+    typedef Blk4Tiles<CP> T;
+    const size_t lds = (size_t)(bwd ? T::END_BWD : T::END_FWD) * sizeof(float);
+    const int nwin = N * (H / 4) * (W / 4);
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int grid = 256 * per_cu * 2;  // two rounds of resident workgroups: evens out windows of unequal cost at no extra LDS
+    if (grid > nwin) grid = nwin;
+    static bool set_f = false, set_b = false;
+    bool& set = bwd ? set_b : set_f;
+    if (!set) {
+        hipError_t e = bwd ? hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_bwd_blk4_kernel<CP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_fwd_blk4_kernel<CP>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_blk4)");
+        set = true;
+    }
+    if (bwd) hipLaunchKernelGGL((attn_core_bwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, d_o, out, N, H, W, C);
+    else hipLaunchKernelGGL((attn_core_fwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, out, N, H, W, C);
+    MSTG_CHECK_LAUNCH("attn_core_blk4_kernel");
+    return MSTG_OK;
+}
+
 template <int CP>
 static int launch_attn_blk(bool bwd, const float* qkv, const float* d_o, float* out, int N, int H, int W, int C, hipStream_t st) {
     typedef BlkTiles<CP> T;
     const size_t lds = (size_t)(bwd ? T::END_BWD : T::END_FWD) * sizeof(float);
     const int nwin = N * (H / 4) * (W / 4);
-    int grid = 256 * 4;
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 4 ? 4 : (per_cu > 8 ? 8 : per_cu);
+    int grid = 256 * per_cu;
     if (grid > nwin) grid = nwin;
     static bool set_f = false, set_b = false;
     bool& set = bwd ? set_b : set_f;
@@ -850,6 +1111,17 @@ static int launch_attn_blk(bool bwd, const float* qkv, const float* d_o, float* 
     else hipLaunchKernelGGL((attn_core_fwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
     MSTG_CHECK_LAUNCH("attn_core_blk_kernel");
     return MSTG_OK;
+}
+
+static bool attn_blk4() {  // MSTG_ATTN_BLK4=0: one wave per window also above 64 channels
+    const char* e = getenv("MSTG_ATTN_BLK4");
+    return !(e && e[0] == '0');
+}
+static bool attn_blk64() {
+    // 32 < C <= 64: the row-blocked kernel needs 26 KB of LDS per wave instead of 43 KB (6 waves per CU instead of 3) and was
+    // 1.4x (forward) / 1.65x (backward) faster at 256x256, C = 64; MSTG_ATTN_BLK64=0 selects the whole-matrix kernel
+    const char* e = getenv("MSTG_ATTN_BLK64");
+    return !(e && e[0] == '0');
 }
 
 static int attn_check(int N, int H, int W, int C) {
@@ -893,9 +1165,9 @@ extern "C" int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int 
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16) return launch_attn<16>(false, qkv, nullptr, o, N, H, W, C, st);
     if (C <= 32) return launch_attn<32>(false, qkv, nullptr, o, N, H, W, C, st);
-    if (C <= 64) return launch_attn<64>(false, qkv, nullptr, o, N, H, W, C, st);
-    if (C <= 128) return launch_attn_blk<128>(false, qkv, nullptr, o, N, H, W, C, st);
-    return launch_attn_blk<256>(false, qkv, nullptr, o, N, H, W, C, st);
+    if (C <= 64) return attn_blk64() ? launch_attn_blk<64>(false, qkv, nullptr, o, N, H, W, C, st) : launch_attn<64>(false, qkv, nullptr, o, N, H, W, C, st);
+    if (C <= 128) return attn_blk4() ? launch_attn_blk4<128>(false, qkv, nullptr, o, N, H, W, C, st) : launch_attn_blk<128>(false, qkv, nullptr, o, N, H, W, C, st);
+    return attn_blk4() ? launch_attn_blk4<256>(false, qkv, nullptr, o, N, H, W, C, st) : launch_attn_blk<256>(false, qkv, nullptr, o, N, H, W, C, st);
 }
 
 extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C,
@@ -905,9 +1177,9 @@ extern "C" int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, flo
     hipStream_t st = (hipStream_t)stream;
     if (C <= 16) return launch_attn<16>(true, qkv, d_o, dqkv, N, H, W, C, st);
     if (C <= 32) return launch_attn<32>(true, qkv, d_o, dqkv, N, H, W, C, st);
-    if (C <= 64) return launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
-    if (C <= 128) return launch_attn_blk<128>(true, qkv, d_o, dqkv, N, H, W, C, st);
-    return launch_attn_blk<256>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    if (C <= 64) return attn_blk64() ? launch_attn_blk<64>(true, qkv, d_o, dqkv, N, H, W, C, st) : launch_attn<64>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    if (C <= 128) return attn_blk4() ? launch_attn_blk4<128>(true, qkv, d_o, dqkv, N, H, W, C, st) : launch_attn_blk<128>(true, qkv, d_o, dqkv, N, H, W, C, st);
+    return attn_blk4() ? launch_attn_blk4<256>(true, qkv, d_o, dqkv, N, H, W, C, st) : launch_attn_blk<256>(true, qkv, d_o, dqkv, N, H, W, C, st);
 }
 
 #ifdef MSTG_STAMPS

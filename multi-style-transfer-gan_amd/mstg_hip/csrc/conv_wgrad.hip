@@ -502,7 +502,7 @@ static bool wgrad_1x1_ok(const WGradArgs& a) {
     const char* e = getenv("MSTG_WGRAD_1X1");
     if (e && e[0] == '0') return false;
     return a.T == 1 && a.stride == 1 && !a.g_nchw && !a.h_nchw && ((a.g_ctot | a.g_coff | a.Cg | a.h_ctot | a.h_coff | a.Ch) & 3) == 0 &&
-           a.Cg <= 64 && a.Ch <= 192 && a.Cg * a.Ch >= 256;
+           a.Cg * a.Ch >= 256;
 }
 static int wgrad_1x1_splits(const WGradArgs& a) {
     const int P1 = wgrad_1x1_tile(a.Cg, a.Ch);
@@ -510,6 +510,36 @@ static int wgrad_1x1_splits(const WGradArgs& a) {
     long S = 1024;
     if (S > ntiles) S = ntiles;
     return (int)S;
+}
+// Wider layers (the class-default generator has 128 -> 384 and 256 -> 768) are cut into (<= 64 input, <= 192 output) channel
+// blocks, one launch each on the same pixels: x is then read Ch/192 times and dy Cg/64 times, against Ch/32 and Cg/16 times in
+// the generic kernel.  Block widths are multiples of 16 and as even as the channel counts allow.
+struct W11Chunks {
+    int ng, nh, wg, wh;  // number of blocks and block width (last one may be narrower) along Cg / Ch
+};
+static W11Chunks wgrad_1x1_chunks(const WGradArgs& a) {
+    W11Chunks c;
+    c.ng = cdiv(a.Cg, 64);
+    c.nh = cdiv(a.Ch, 192);
+    c.wg = c.ng == 1 ? a.Cg : cdiv(cdiv(a.Cg, c.ng), 16) * 16;
+    c.wh = c.nh == 1 ? a.Ch : cdiv(cdiv(a.Ch, c.nh), 16) * 16;
+    c.ng = cdiv(a.Cg, c.wg);
+    c.nh = cdiv(a.Ch, c.wh);
+    return c;
+}
+static WGradArgs wgrad_1x1_block(const WGradArgs& a, const W11Chunks& c, int ig, int ih) {
+    WGradArgs b = a;
+    b.g_coff = a.g_coff + ig * c.wg;
+    b.Cg = a.Cg - ig * c.wg < c.wg ? a.Cg - ig * c.wg : c.wg;
+    b.h_coff = a.h_coff + ih * c.wh;
+    b.Ch = a.Ch - ih * c.wh < c.wh ? a.Ch - ih * c.wh : c.wh;
+    b.with_bias = a.with_bias && ig == 0;
+    return b;
+}
+static size_t wgrad_1x1_workspace(const WGradArgs& a) {
+    const W11Chunks c = wgrad_1x1_chunks(a);
+    const WGradArgs b = wgrad_1x1_block(a, c, 0, 0);  // the widest block
+    return (size_t)wgrad_1x1_splits(b) * ((size_t)b.Cg * b.Ch + b.Ch) * sizeof(float);
 }
 
 // dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]  (+ dbias[hch] from the tail of each split's block).
@@ -690,7 +720,8 @@ extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass
     if (check_desc(d) || fill_wgrad_args(d, nullptr, nullptr, a)) return "";
     const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch();
     if (wgrad_1x1_ok(a)) {
-        snprintf(name, sizeof(name), "wgrad_1x1_kernel<%d, %d>", cdiv(a.Cg, 16), cdiv(cdiv(a.Ch, 16), 4));
+        const WGradArgs b = wgrad_1x1_block(a, wgrad_1x1_chunks(a), 0, 0);
+        snprintf(name, sizeof(name), "wgrad_1x1_kernel<%d, %d>", cdiv(b.Cg, 16), cdiv(cdiv(b.Ch, 16), 4));
     } else if (use_ts) {
         snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", plan_ts(a).UW);
     } else {
@@ -706,7 +737,7 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
     const size_t w_old = plan_wgrad(a).ws_bytes;
     const size_t w_ts = (a.Teff == 16 && a.mode == MODE_PLAIN) ? plan_ts(a).ws_bytes : 0;  // the only shapes the tap-split kernel takes
-    const size_t w_11 = wgrad_1x1_ok(a) ? (size_t)wgrad_1x1_splits(a) * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float) : 0;
+    const size_t w_11 = wgrad_1x1_ok(a) ? wgrad_1x1_workspace(a) : 0;
     size_t w = w_old > w_ts ? w_old : w_ts;
     return w > w_11 ? w : w_11;
 }
@@ -727,17 +758,29 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     // stride-2 / transposed 4x4 layers with 17..32 grid channels); the pixel-split kernel elsewhere
     const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch();
     if (wgrad_1x1_ok(a)) {
-        S = wgrad_1x1_splits(a);
-        if (workspace_bytes < (size_t)S * ((size_t)a.Cg * a.Ch + a.Ch) * sizeof(float))
-            return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+        if (workspace_bytes < wgrad_1x1_workspace(a)) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
         const long P = (long)a.N * a.hH * a.hW;
-        const int MF = cdiv(a.Cg, 16), NW = cdiv(cdiv(a.Ch, 16), 4);
-        int rc = MSTG_E_UNSUPPORTED;
-#define MSTG_W11(M_, N_) if (MF == M_ && NW == N_) rc = launch_wgrad_1x1<M_, N_>(a, P, S, st);
-        MSTG_W11(1, 1) MSTG_W11(1, 2) MSTG_W11(1, 3) MSTG_W11(2, 1) MSTG_W11(2, 2) MSTG_W11(2, 3) MSTG_W11(3, 1) MSTG_W11(3, 2) MSTG_W11(3, 3)
-        MSTG_W11(4, 1) MSTG_W11(4, 2) MSTG_W11(4, 3)
+        const W11Chunks c = wgrad_1x1_chunks(a);
+        const int s_g = 1, s_h = d->transposed ? d->Cout : d->Cin;  // T == 1
+        for (int ig = 0; ig < c.ng; ++ig)
+            for (int ih = 0; ih < c.nh; ++ih) {
+                const WGradArgs b = wgrad_1x1_block(a, c, ig, ih);
+                const int Sb = wgrad_1x1_splits(b);
+                const int MF = cdiv(b.Cg, 16), NW = cdiv(cdiv(b.Ch, 16), 4);
+                int rc = MSTG_E_UNSUPPORTED;
+#define MSTG_W11(M_, N_) if (MF == M_ && NW == N_) rc = launch_wgrad_1x1<M_, N_>(b, P, Sb, st);
+                MSTG_W11(1, 1) MSTG_W11(1, 2) MSTG_W11(1, 3) MSTG_W11(2, 1) MSTG_W11(2, 2) MSTG_W11(2, 3) MSTG_W11(3, 1) MSTG_W11(3, 2)
+                MSTG_W11(3, 3) MSTG_W11(4, 1) MSTG_W11(4, 2) MSTG_W11(4, 3)
 #undef MSTG_W11
-        if (rc) return rc;
+                if (rc) return rc;
+                // the partial slabs are reused by the next block: stream order keeps this reduce ahead of the next launch
+                const int pstride = b.Cg * b.Ch + (b.with_bias ? b.Ch : 0);
+                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial,
+                                   dw + (size_t)(ig * c.wg) * s_g + (size_t)(ih * c.wh) * s_h, b.with_bias ? dbias + ih * c.wh : nullptr, Sb, 1,
+                                   b.Cg, b.Ch, s_g, s_h, pstride, d->accumulate);
+                MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
+            }
+        return MSTG_OK;
     } else if (use_ts && !(getenv("MSTG_WGRAD_OLD") && getenv("MSTG_WGRAD_OLD")[0] == '1')) {
         const TsPlan p = plan_ts(a);
         if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");

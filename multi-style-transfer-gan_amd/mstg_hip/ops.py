@@ -405,6 +405,15 @@ class BatchNormActFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------------------------------------
 # window attention core
 # ----------------------------------------------------------------------------------------------------------
+def _attn_core_symbol(direction, Cn):
+    """Kernel symbol attention.hip launches for this width (for the timing table only)."""
+    if Cn <= 32 or (Cn <= 64 and os.environ.get("MSTG_ATTN_BLK64", "1") == "0"):
+        return f"attn_core_{direction}_kernel<{16 if Cn <= 16 else (32 if Cn <= 32 else 64)}>"
+    if Cn <= 64 or os.environ.get("MSTG_ATTN_BLK4", "1") == "0":
+        return f"attn_core_{direction}_blk_kernel<{64 if Cn <= 64 else (128 if Cn <= 128 else 256)}>"
+    return f"attn_core_{direction}_blk4_kernel<{128 if Cn <= 128 else 256}>"
+
+
 class WindowAttnCoreFn(torch.autograd.Function):
     """o = attn(q^, k^) v per 4x4 window; qkv NHWC (N,H,W,3C) -> o NHWC (N,H,W,C)."""
 
@@ -414,9 +423,8 @@ class WindowAttnCoreFn(torch.autograd.Function):
         N, H, W, C3 = qkv.shape
         Cn = C3 // 3
         o = torch.empty((N, H, W, Cn), dtype=torch.float32, device=qkv.device)
-        cp = 16 if Cn <= 16 else (32 if Cn <= 32 else 64)
-        _timed(f"attn_core_fwd_kernel<{cp}>", 4 * Cn * Cn * N * H * W, 4 * 4 * Cn * N * H * W, lambda: _lib.check(
-            _lib.load().mstg_window_attn_core_fwd(_p(qkv), _p(o), N, H, W, Cn, _stream()), "mstg_window_attn_core_fwd"))
+        _timed(_attn_core_symbol('fwd', Cn), 4 * Cn * Cn * N * H * W, 4 * 4 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_core_fwd(_p(qkv), _p(o), N, H, W, Cn, _stream()), "mstg_window_attn_core_fwd"), detail=f"attn-core N{N} {H}x{W} C{Cn}")
         ctx.save_for_backward(qkv)
         return o
 
@@ -427,9 +435,8 @@ class WindowAttnCoreFn(torch.autograd.Function):
         N, H, W, C3 = qkv.shape
         dqkv = torch.empty_like(qkv)
         Cn = C3 // 3
-        cp = 16 if Cn <= 16 else (32 if Cn <= 32 else 64)
-        _timed(f"attn_core_bwd_kernel<{cp}>", 12 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
-            _lib.load().mstg_window_attn_core_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, _stream()), "mstg_window_attn_core_bwd"))
+        _timed(_attn_core_symbol('bwd', Cn), 12 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_core_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, _stream()), "mstg_window_attn_core_bwd"), detail=f"attn-core N{N} {H}x{W} C{Cn}")
         return dqkv
 
 

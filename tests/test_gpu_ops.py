@@ -70,6 +70,9 @@ CONV_CASES = [
     ("1x1 16->48", 2, 16, 24, 16, 48, 1, 1, 0, 1, 0, 0, 0, 0),
     ("1x1 64->192", 1, 8, 8, 64, 192, 1, 1, 0, 1, 0, 0, 0, 0),
     ("1x1 8->24", 2, 8, 12, 8, 24, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("1x1 128->384 (wgrad in 2x2 channel blocks)", 1, 12, 16, 128, 384, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("1x1 72->200 (uneven channel blocks)", 2, 8, 12, 72, 200, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("1x1 256->32", 1, 8, 8, 256, 32, 1, 1, 0, 1, 0, 0, 0, 0),
     ("k4s1p1 64->1 (D head)", 2, 4, 4, 64, 1, 4, 1, 1, 1, 0, 0, 0, 0),
     ("k4s1p1 128->1 16x16", 2, 16, 16, 128, 1, 4, 1, 1, 1, 0, 0, 0, 0),
     ("k3 d1 ragged 13x21 4->5", 1, 13, 21, 4, 5, 3, 1, 1, 1, 0, 0, 0, 0),
@@ -198,7 +201,7 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
 
 
 @pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
-                                 "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1"])
+                                 "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0"])
 def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
@@ -208,6 +211,12 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     for case in CONV_CASES:
         if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4"):
             test_conv_fwd_bwd(case)
+    if k == "MSTG_ATTN_BLK64":
+        test_window_attention_core(2, 8, 8, 64)
+        test_window_attention_core(1, 8, 4, 48)
+    if k == "MSTG_ATTN_BLK4":
+        for shape in ((2, 8, 8, 128), (1, 4, 8, 256), (1, 8, 4, 96), (1, 4, 4, 200)):
+            test_window_attention_core(*shape)
 
 
 NORM_CASES = [(2, 16, 24, 8, 1), (1, 64, 64, 16, 1), (3, 7, 9, 32, 2), (2, 4, 4, 64, 2), (1, 128, 128, 16, 1), (2, 2, 2, 64, 2),
@@ -284,7 +293,8 @@ def _attn_core_ref(qkv, C):
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 8), (1, 4, 8, 16), (2, 16, 16, 16), (1, 16, 8, 32), (2, 8, 8, 64), (1, 64, 64, 16),
-                                     (1, 4, 4, 4), (1, 8, 8, 24), (1, 8, 4, 48), (2, 8, 8, 128), (1, 4, 8, 256), (1, 8, 4, 96), (1, 4, 4, 200)])
+                                     (1, 4, 4, 4), (1, 8, 8, 24), (1, 8, 4, 48), (2, 8, 8, 128), (1, 4, 8, 256), (1, 8, 4, 96), (1, 4, 4, 200), (2, 96, 128, 128),
+                                     (1, 64, 96, 256)])
 def test_window_attention_core(N, H, W, C):
     from mstg_hip import ops
     qkv = rnd((N, 3 * C, H, W), 51 + C, 2.0)
