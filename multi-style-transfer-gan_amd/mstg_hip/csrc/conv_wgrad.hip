@@ -52,6 +52,16 @@ struct WGradArgs {
 };
 
 constexpr int WT_H = 8, WT_W = 16;
+
+// Phase time stamps of sampled tap-split workgroups, third tile of each (tools/diag_stamps_wgrad.py); only with -DMSTG_STAMPS.
+#ifdef MSTG_STAMPS
+__device__ unsigned long long g_wg_stamps[2 * 64 * 8];
+#define WG_STAMP(k)                                                                                                          \
+    if (tcount == 2 && (threadIdx.x == 0 || threadIdx.x == 192) && (blockIdx.x % 11) == 0 && blockIdx.x / 11 < 64 && blockIdx.y == 0) \
+        g_wg_stamps[((threadIdx.x != 0) * 64 + blockIdx.x / 11) * 8 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define WG_STAMP(k)
+#endif
 #ifndef WG_WAVES
 #define WG_WAVES 4  // waves per SIMD the register allocation must allow (4 -> <= 128 VGPRs): measured +10-15 % on the
                     // small-channel layers (7x7, 16<->32 4x4); the 16-tap variant with 64-channel operands is faster left alone
@@ -180,8 +190,12 @@ __global__ __launch_bounds__(256, (TG >= 16 ? 2 : WG_WAVES)) void wgrad_kernel(c
         for (int hf = 0; hf < NFH; ++hf) acc[t][hf] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // Conv2d bias gradient = column sums of the grid tensor.  All 256 threads share the tile's 128 pixels (thread = column
+    // bcol, pixel phase bpart); a single wave summing them serially held the other three at the next barrier for ~5k cycles
+    // per tile (tools/diag_stamps_wgrad.py).  The phases are combined in fixed order after the tile loop.
     const bool do_bias = a.with_bias && gchunk == 0 && blockIdx.z == 0;
-    float bsum = 0.f;  // thread c < BN: running column sum of grid channel h0 + c
+    const int bcols = mode == MODE_DPACK ? 4 : BN, bparts = 256 / bcols, bcol = tid % bcols, bpart = tid / bcols;
+    float bsum = 0.f;
     const unsigned m_pw = magic_u32(a.PW), m_htw = magic_u32(a.htw);
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
@@ -190,14 +204,13 @@ __global__ __launch_bounds__(256, (TG >= 16 ? 2 : WG_WAVES)) void wgrad_kernel(c
         __syncthreads();
         wgrad_stage(a, patch, ht, n, ty0, gx0, y0, x0, g0, h0, WT_H, BN / 4, BNP, m_pw, m_htw, magic_u32(BN / 4), tid);
         __syncthreads();
-        if (do_bias && mode != MODE_DPACK && tid < BN) {
-#pragma unroll 8
-            for (int p = 0; p < 128; ++p) bsum += ht[p * BNP + tid];
+        if (do_bias && mode != MODE_DPACK) {
+#pragma unroll 4
+            for (int p = bpart; p < 128; p += bparts) bsum += ht[p * BNP + bcol];
         }
-        if (do_bias && mode == MODE_DPACK && tid < 4) {  // the tile's own 16 columns sit 3 pixels into the [8][htw][4] tile
-            for (int r = 0; r < WT_H; ++r)
-#pragma unroll 8
-                for (int c = 0; c < 16; ++c) bsum += ht[(r * a.htw + c + 3) * 4 + tid];
+        if (do_bias && mode == MODE_DPACK) {  // the tile's own 16 columns sit 3 pixels into the [8][htw][4] tile
+#pragma unroll
+            for (int p = bpart; p < 128; p += 64) bsum += ht[((p >> 4) * a.htw + (p & 15) + 3) * 4 + bcol];
         }
         // ---- MFMA: this wave's two tile rows, 4 pixels per k-step --------------------------------------------------
         const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
@@ -224,6 +237,15 @@ __global__ __launch_bounds__(256, (TG >= 16 ? 2 : WG_WAVES)) void wgrad_kernel(c
 
     // ---- sum the four waves through LDS (fixed order), then write this workgroup's partial --------------------
     __syncthreads();
+    if (do_bias) {  // wave-uniform
+        smem[tid] = bsum;
+        __syncthreads();
+        if (tid < bcols) {
+            bsum = 0.f;
+            for (int j = 0; j < bparts; ++j) bsum += smem[tid + bcols * j];
+        }
+        __syncthreads();
+    }
     float* red = smem;  // [TG*NFH][256]
     for (int wv = 1; wv < 4; ++wv) {
         if (wave == wv) {
@@ -296,7 +318,7 @@ __global__ __launch_bounds__(256, WG_WAVES) void wgrad_ts_kernel(const WGradArgs
     const int U = a.Teff * NFHT;  // units of this workgroup; unit u -> tap u / NFHT, fragment u % NFHT
 
     f32x4 acc[UW];
-    int toff[UW], hfo[UW];
+    int toff[UW];
 #pragma unroll
     for (int k = 0; k < UW; ++k) {
         const int u = min(wave + 4 * k, U - 1);
@@ -306,42 +328,68 @@ __global__ __launch_bounds__(256, WG_WAVES) void wgrad_ts_kernel(const WGradArgs
         else if (mode == MODE_PACKX) { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx); }
         else { ky = tt / a.tapsx; kxo = 4 * (tt % a.tapsx) + 3; }
         toff[k] = (ky * a.dil * a.PW + kxo) * ckp;
-        hfo[k] = 16 * hf;
         acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int nu = (U - wave + 3) / 4;  // units this wave really owns
+    const int hfo0 = 16 * (min(wave, U - 1) % NFHT);
 
     const bool do_bias = a.with_bias && gchunk == 0;
-    float bsum = 0.f;  // thread c < 16*NFHT: running column sum of grid channel h0 + c
+    const int bcols = 16 * NFHT, bparts = 256 / bcols, bcol = tid % bcols, bpart = tid / bcols;  // as in wgrad_kernel
+    float bsum = 0.f;
     const unsigned m_pw = magic_u32(a.PW), m_htw = magic_u32(a.htw), m_nqh = magic_u32(4 * NFHT);
     const int hrow = mode == MODE_DPACK ? a.htw * 4 : 16 * BNP, hcol = mode == MODE_DPACK ? 4 : BNP;
+#ifdef MSTG_STAMPS
+    int tcount = 0;
+#endif
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
         const int gx0 = tx0 * WT_W - a.xshift;
         const int y0 = ty0 * TH * s - a.pad, x0 = gx0 * s - a.pad;
+        WG_STAMP(0)
         __syncthreads();
+        WG_STAMP(1)
         wgrad_stage(a, patch, ht, n, ty0, gx0, y0, x0, g0, h0, TH, 4 * NFHT, BNP, m_pw, m_htw, m_nqh, tid);
+        WG_STAMP(2)
         __syncthreads();
-        if (do_bias && tid < 16 * NFHT) {
-            for (int p = 0; p < TH * 16; ++p) bsum += ht[p * BNP + tid];
+        WG_STAMP(3)
+        if (do_bias && bpart < bparts) {
+#pragma unroll 4
+            for (int p = bpart; p < TH * 16; p += bparts) bsum += ht[p * BNP + bcol];
         }
+        WG_STAMP(4)
         // ---- MFMA: every wave walks all TH x 16 pixels (4 per k-step) for its own units -----------------------------------
 #pragma unroll 1
         for (int r = 0; r < TH; ++r) {
-#pragma unroll 1
-            for (int xs = 0; xs < 4; ++xs) {
+#pragma unroll 2
+            for (int xs = 0; xs < 4; ++xs) {  // two k-steps per iteration: the second step's LDS reads are in flight behind the first's MFMAs
                 const int c = 4 * xs + g;
                 const int abase = (r * s * a.PW + c * s) * ckp + i;
                 const int hbase = r * hrow + c * hcol + i;
-                float af[UW], bf[UW];  // units beyond nu repeat the last real unit: their accumulators are never written out
+                float af[UW];  // units beyond nu repeat the last real unit: their accumulators are never written out
+                // NFHT divides 4 (launch_ts_t checks): unit u = wave + 4k uses fragment u % NFHT = wave % NFHT for every k,
+                // so ONE B read serves all of this wave's units
+                const float b = ht[hbase + hfo0];
 #pragma unroll
-                for (int k = 0; k < UW; ++k) { af[k] = patch[abase + toff[k]]; bf[k] = ht[hbase + hfo[k]]; }
+                for (int k = 0; k < UW; ++k) af[k] = patch[abase + toff[k]];
 #pragma unroll
-                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af[k], bf[k], acc[k]);
+                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af[k], b, acc[k]);
             }
         }
+        WG_STAMP(5)
+#ifdef MSTG_STAMPS
+        ++tcount;
+#endif
     }
     // ---- each wave writes the partial of its own units; no cross-wave reduction ------------------------------------------
+    if (do_bias) {  // wave-uniform: combine the pixel phases in fixed order
+        __syncthreads();
+        smem[tid] = bpart < bparts ? bsum : 0.f;
+        __syncthreads();
+        if (tid < bcols) {
+            bsum = 0.f;
+            for (int j = 0; j < bparts; ++j) bsum += smem[tid + bcols * j];
+        }
+    }
     const size_t pstride = (size_t)a.T * a.Cg * a.Ch + (a.with_bias ? a.Ch : 0);
     if (do_bias && tid < 16 * NFHT && h0 + tid < a.Ch) a.partial[(size_t)blockIdx.x * pstride + (size_t)a.T * a.Cg * a.Ch + h0 + tid] = bsum;
     float* out = a.partial + (size_t)blockIdx.x * pstride;
@@ -660,6 +708,7 @@ static TsPlan plan_ts(WGradArgs& a) {
 template <int UW>
 static int launch_ts_t(WGradArgs& a, const TsPlan& p, hipStream_t st) {
     if (p.lds > 160 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: LDS patch too large");
+    if (4 % p.NFHT) return fail_arg(MSTG_E_UNSUPPORTED, "wgrad: tap-split kernel needs 1, 2 or 4 grid-channel fragments per workgroup");
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ts_kernel<UW>),
@@ -814,3 +863,9 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;
 }
+
+#ifdef MSTG_STAMPS
+extern "C" int mstg_debug_stamps_wgrad(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mstg::g_wg_stamps), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+#endif
