@@ -304,8 +304,10 @@ __global__ __launch_bounds__(256, (TG >= 16 ? 2 : WG_WAVES)) void wgrad_kernel(c
 // patch (4x less re-staging), a wave keeps only UW accumulators (occupancy), and no cross-wave reduction is needed.
 // TH (4 or 8) is the tile height: stride-2 patches are large, a 4-row tile keeps three workgroups per CU.
 // =====================================================================================================================
+// Register budget of three waves per SIMD: the launch puts three workgroups on a CU (768 in all), and at four (128 VGPRs) the
+// compiler spilled 45 registers around the staging (scratch traffic on every tile).
 template <int UW>
-__global__ __launch_bounds__(256, WG_WAVES) void wgrad_ts_kernel(const WGradArgs a, const int TH, const int NFHT) {
+__global__ __launch_bounds__(256, 3) void wgrad_ts_kernel(const WGradArgs a, const int TH, const int NFHT) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ckp = a.ckp, s = a.stride, mode = a.mode;
     const int BNP = 16 * NFHT + 4;
