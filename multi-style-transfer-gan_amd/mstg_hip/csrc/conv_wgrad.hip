@@ -63,8 +63,9 @@ __device__ unsigned long long g_wg_stamps[2 * 64 * 8];
 #define WG_STAMP(k)
 #endif
 #ifndef WG_WAVES
-#define WG_WAVES 4  // waves per SIMD the register allocation must allow (4 -> <= 128 VGPRs): measured +10-15 % on the
-                    // small-channel layers (7x7, 16<->32 4x4); the 16-tap variant with 64-channel operands is faster left alone
+#define WG_WAVES 3  // waves per SIMD the register allocation must allow (3 -> <= 168 VGPRs, no scratch spills) = workgroups per CU the
+                    // launches create.  Uncapped the compiler took up to 250 registers (one or two waves per SIMD: 10-15 % slower on
+                    // the small-channel layers); at 4 (128 VGPRs) the 7x7 and 3x3 variants spilled 8-47 registers around the staging
 #endif
 
 // Stage one tile's gathered patch and grid-tensor tile into LDS (shared by both kernels).  The aligned NHWC cases and the
@@ -638,7 +639,7 @@ static WGradPlan plan_wgrad(const WGradArgs& a) {
     p.nz = cdiv(a.Teff, p.tg);
     p.TGn = cdiv(a.Teff, p.nz);
     const int ny = a.n_gchunks * (a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16 * p.nfh));
-    int S = 1024 / (ny * p.nz);
+    int S = (p.tg >= 16 ? 1024 : 256 * WG_WAVES) / (ny * p.nz);  // as many workgroups as the register budget keeps resident
     // keep the partial slabs small: they are written once and re-read once by the reduce kernel
     const size_t slab = ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
     while (S > 256 && (size_t)S * slab > ((size_t)48 << 20)) S >>= 1;
