@@ -1,27 +1,40 @@
-"""Benchmark of the hot path: the CycleGAN training step of the reference (enhanced_train.py:59-131) -- 6 generator
-forwards + 10 discriminator forwards, backward through all of them, two Adam steps -- on N MI355X, one process per
-GPU, image batches sharded data-parallel with one RCCL all-reduce per optimizer.
+"""Benchmark of the hot path on N MI355X, one process per GPU, image batches sharded data-parallel with one RCCL all-reduce
+per optimizer.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1..5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one train step on a per-rank batch of 32 image pairs at 256x256 (synthetic uniform [-1,1) data, random
-init of the reference architecture at channels=16: what enhanced_train.py:18-21 trains).  Weak scaling: the per-GPU
-batch is fixed.  Rank 0 prints ONE JSON line.  An "image" is one input image pushed through the step; a step consumes
-2 * batch images (one per domain), so value = 2 * batch * N / step_time.
+Started WITHOUT a launcher and with --gpus N > 1, this script itself starts the N ranks (a torch.distributed.run child,
+before anything in this process has touched the GPU) and exits with the child's code; a rank whose world size or backend is
+not what --gpus asked for exits non-zero -- a 1-GPU number is never reported under an N-GPU label.
+
+--config selects one of the five BASELINE.json workloads (default 3 = the one the headline metric is quoted on):
+  1  EnhancedGenerator forward, one 256x256 image (direct_transform.py:44-79), fp32
+  2  EnhancedGenerator forward + backward (loss mean|y|), batch 16 at 256x256, fp32
+  3  the reference's CycleGAN train step (enhanced_train.py:59-131): 6 generator + 10 discriminator forwards, backward through
+     all of them, two Adam steps; 32 image pairs per GPU at 256x256, fp32   [--style-loss adds the build-defined VGG/Gram loss]
+  4  the same step at 512x512, 32 pairs per GPU, with the build-defined multi-style loss (3 weighted references), data parallel
+  5  inference-only EnhancedGenerator forward, batch 64 at 1024x1024, fp16 storage + fp16 MFMA with fp32 accumulation
+One "step" = one pass of the configured workload on the per-rank batch (synthetic uniform [-1,1) data, random init of the
+reference architecture at channels=16: what enhanced_train.py:18-21 trains).  Weak scaling: the per-GPU batch is fixed.  Rank 0
+prints ONE JSON line.  An "image" is one input image pushed through the step; a train step consumes 2 * batch images (one per
+domain), so value = 2 * batch * N / step_time there, and batch * N / step_time for the generator-only configs.
 
 Besides the contract fields the line carries
-  roofline     : the kernel symbol with the largest share of GPU time, measured with HIP events around every launch of
-                 an instrumented step that follows the timed region (same stream, same shapes): achieved = sum of
-                 algorithmic FLOPs (or bytes) of its launches / sum of their durations, against the MI355X peak;
-  cpu_baseline : the oracle's restatement of the same train step (oracle/restatement.py, validated against the reference
-                 in the build container) timed on this box's host cores on a bounded sample (batch 1, 256x256).
+  roofline     : the kernel symbol with the largest share of GPU time, measured with HIP events around every launch of an
+                 instrumented step that follows the timed region (same stream, same shapes): achieved = sum of algorithmic
+                 FLOPs (or bytes) of its launches / sum of their durations, against the MI355X peak;
+  cpu_baseline : the oracle's restatement of the same workload (oracle/restatement.py, validated against the reference in the
+                 build container) timed on this box's host cores on a bounded sample; thread counts {1, 8, 32, all} are swept
+                 and the best is `value` (the 1-thread figure is reported beside it).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +47,17 @@ for p in (ROOT, PKG):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
-PEAK_HBM_GBS = 8000.0         # HBM3E spec
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: BF16/FP16 MFMA, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+CONFIGS = {
+    1: dict(kind="fwd", batch=1, size=256, dtype="f32", style=False),
+    2: dict(kind="fwdbwd", batch=16, size=256, dtype="f32", style=False),
+    3: dict(kind="train", batch=32, size=256, dtype="f32", style=False),
+    4: dict(kind="train", batch=32, size=512, dtype="f32", style=True),
+    5: dict(kind="fwd", batch=64, size=1024, dtype="f16", style=False),
+}
 
 
 def parse():
@@ -43,77 +65,211 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU per step")
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json workload (see module docstring)")
+    ap.add_argument("--batch", type=int, default=None, help="images (generator configs) / image pairs (train step) per GPU per step")
+    ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--channels", type=int, default=16)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default=None, help="forward-only configs: storage/MFMA type")
     ap.add_argument("--style-loss", action="store_true",
-                    help="add the build-defined VGG/Gram multi-style loss (3 weighted references) to the step; NOT the headline workload")
+                    help="add the build-defined VGG/Gram multi-style loss (3 weighted references) to the train step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="print the per-kernel table of the instrumented step to stderr")
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    args.kind = cfg["kind"]
+    args.batch = cfg["batch"] if args.batch is None else args.batch
+    args.size = cfg["size"] if args.size is None else args.size
+    args.dtype = cfg["dtype"] if args.dtype is None else args.dtype
+    args.style_loss = bool(args.style_loss or cfg["style"])
+    if args.dtype == "f16" and args.kind != "fwd":
+        ap.error("fp16 is the inference (forward-only) path; training runs in fp32")
+    return args
 
 
-def cpu_baseline(channels: int, size: int):
-    """The oracle's train step on the host cores: batch 1, 1 warm-up + timed steps bounded to ~20 s."""
+# ------------------------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N  (no torchrun)  ->  N ranks as a child torch.distributed.run
+# ------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script.  Nothing here initialises the GPU (device_count() does not, on this image), so the child
+    is started from a clean process; the parent only waits and forwards the exit code."""
+    rehearse = os.environ.get("MSTG_BENCH_REHEARSE", "0") == "1"
+    have = torch.cuda.device_count()
+    if have < n and not rehearse:
+        print(f"[bench] --gpus {n} but this node shows {have} GPU(s): refusing to report a {have}-GPU number as {n}-GPU "
+              f"(MSTG_BENCH_REHEARSE=1 rehearses the N-rank flow on one GPU over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle -- the checker, timed here only as the reported baseline)
+# ------------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(args):
+    """The oracle's restatement of the configured workload on the host cores, bounded to roughly 60 s: thread counts
+    {1, 8, 32, all} at batch 1 (one timed pass each after a small warm-up that builds oneDNN's primitives), then batch 4 at the
+    best thread count.  value = best images/s found; the 1-thread figure is reported beside it."""
     from oracle import restatement as R
+    C, size, kind = args.channels, args.size, args.kind
+    if kind != "train":
+        size = min(size, 512)  # 1024x1024 on the CPU is minutes per image; the per-pixel cost is size-independent (stated in `sample`)
     torch.manual_seed(0)
-    threads = torch.get_num_threads()
-    sds = [R.make_state_dict(R.generator_spec(channels), 11), R.make_state_dict(R.generator_spec(channels), 12),
-           R.make_state_dict(R.discriminator_spec(channels), 13), R.make_state_dict(R.discriminator_spec(channels), 14)]
-    model = R.CycleGANOracle(*sds)
-    a, b = R.make_input((1, 3, size, size), 21), R.make_input((1, 3, size, size), 22)
-    model.train_step(a, b)
-    t0, n = time.perf_counter(), 0
-    while n < 3 or (time.perf_counter() - t0 < 12.0 and n < 8):
-        model.train_step(a, b)
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": round(2.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle train step, batch 1 pair at {size}x{size}, channels={channels}, {n} timed steps after 1 warm-up, "
-                      f"{threads} torch threads, fp32"}
+    ncpu = os.cpu_count() or 1
+
+    def workload(n):
+        if kind == "train":
+            sds = [R.make_state_dict(R.generator_spec(C), 11), R.make_state_dict(R.generator_spec(C), 12),
+                   R.make_state_dict(R.discriminator_spec(C), 13), R.make_state_dict(R.discriminator_spec(C), 14)]
+            model = R.CycleGANOracle(*sds)
+            a, b = R.make_input((n, 3, size, size), 21), R.make_input((n, 3, size, size), 22)
+            return (lambda: model.train_step(a, b)), 2 * n
+        sd = R.make_state_dict(R.generator_spec(C), 11)
+        x = R.make_input((n, 3, size, size), 21)
+        if kind == "fwd":
+            def run():
+                with torch.no_grad():
+                    R.generator_forward(sd, x)
+            return run, n
+        params = [v.requires_grad_(True) for k, v in sd.items() if not k.startswith("style_encoder")]
+
+        def run():
+            torch.autograd.grad(R.generator_forward(sd, x).abs().mean(), params)
+        return run, n
+
+    sweep, budget_t0 = [], time.perf_counter()
+    for th in sorted({1, min(8, ncpu), min(32, ncpu), ncpu}):
+        torch.set_num_threads(th)
+        fn, imgs = workload(1)
+        if th == 1 and kind == "train":  # 1 thread: a single cold pass is the sample (a train step is ~10 s there)
+            t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+        else:
+            fn()
+            t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+        sweep.append({"threads": th, "batch": 1, "images_per_sec": round(imgs / dt, 4)})
+    best = max(sweep, key=lambda r: r["images_per_sec"])
+    if time.perf_counter() - budget_t0 < 60.0:
+        torch.set_num_threads(best["threads"])
+        fn, imgs = workload(4)
+        t0 = time.perf_counter(); fn(); dt = time.perf_counter() - t0
+        sweep.append({"threads": best["threads"], "batch": 4, "images_per_sec": round(imgs / dt, 4)})
+        best = max(sweep, key=lambda r: r["images_per_sec"])
+    one = next(r for r in sweep if r["threads"] == 1)
+    torch.set_num_threads(ncpu)
+    what = {"train": "oracle train step", "fwd": "oracle generator forward", "fwdbwd": "oracle generator forward+backward"}[kind]
+    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": best["threads"], "kind": "port",
+            "one_thread_value": one["images_per_sec"], "host_cpus": ncpu, "sweep": sweep,
+            "sample": f"{what} at {size}x{size}, channels={C}, fp32; one timed pass per point after one warm-up pass (1-thread train "
+                      f"step: single pass); best of threads x batch sweep is `value`"}
 
 
 def pmc_traffic(sym: str, args):
-    """HBM bytes per launch of `sym` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs,
-    read side doubled as the MI355X guide prescribes for gfx950; tools/gpu_refresh.sh + tools/pmc_traffic.py).  PMC
-    counters cannot be read from inside this process, so the figure is the one measured on the default workload and is
-    reported only when this run IS the default workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    default = args.batch == 32 and args.size == 256 and args.channels == 16 and not args.style_loss
-    if not default or not os.path.exists(path):
+    """HBM bytes per launch of `sym` from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in separate runs, read side
+    doubled as the MI355X guide prescribes for gfx950; tools/gpu_refresh.sh + tools/pmc_traffic.py).  PMC counters cannot be read
+    from inside this process, so the figure is the one measured on the default workload and is reported only when this run IS
+    the default workload."""
+    default = (args.config == 3 and args.batch == 32 and args.size == 256 and args.channels == 16 and not args.style_loss)
+    if not default:
         return None, None
-    t = json.load(open(path)).get(sym)
-    return (t["hbm_bytes"], "profiles/r01_pmc_traffic.json") if t else (None, None)
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        if os.path.exists(path):
+            t = json.load(open(path)).get(sym)
+            if t:
+                return t["hbm_bytes"], f"profiles/{tag}_pmc_traffic.json"
+    return None, None
+
+
+def metric_label(args) -> str:
+    sz = f"{args.size}x{args.size}"
+    if args.kind == "train":
+        return f"train-step images/sec (fwd+bwd+loss), {sz} batch{args.batch}"
+    if args.kind == "fwdbwd":
+        return f"generator fwd+bwd images/sec, {sz} batch{args.batch}"
+    return f"generator forward images/sec, {sz} batch{args.batch}" + (" fp16" if args.dtype == "f16" else "")
+
+
+def workload_label(args) -> str:
+    sz = f"{args.size}x{args.size}"
+    if args.kind == "train":
+        return (f"config {args.config}: reference CycleGAN train_step (2x EnhancedGenerator + 2x EnhancedDiscriminator, channels={args.channels}, "
+                f"num_transformer_blocks=0), {args.batch} image pairs/GPU at {sz}, fwd+bwd+loss+Adam"
+                + (" + build-defined VGG16/Gram multi-style loss (3 weighted refs)" if args.style_loss else ""))
+    if args.kind == "fwdbwd":
+        return (f"config {args.config}: EnhancedGenerator(channels={args.channels}, num_transformer_blocks=0) forward+backward, loss mean|y|, "
+                f"{args.batch} images/GPU at {sz}")
+    return (f"config {args.config}: EnhancedGenerator(channels={args.channels}, num_transformer_blocks=0) inference forward (no_grad, eval), "
+            f"{args.batch} images/GPU at {sz}, " + ("fp16 storage + fp16 MFMA, fp32 accumulate" if args.dtype == "f16" else "fp32"))
 
 
 def main():
     args = parse()
+    rehearse = os.environ.get("MSTG_BENCH_REHEARSE", "0") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     from mstg_hip import dp, ops
     # MSTG_BENCH_REHEARSE=1: rehearsal of the N > 1 flow on a one-GPU box -- gloo instead of RCCL, every rank on cuda:0
-    rehearse = os.environ.get("MSTG_BENCH_REHEARSE", "0") == "1"
     local = dp.init_from_env("gloo" if rehearse else "nccl")
     if rehearse:
         local = 0
     world = dp.world_size()
     if world != args.gpus:
-        if dp.rank() == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with torch.distributed.run for N>1", file=sys.stderr)
-        args.gpus = world
+        print(f"[bench] world size {world} != --gpus {args.gpus}: refusing to run", file=sys.stderr)
+        sys.exit(2)
+    if world > 1 and not rehearse and dist.get_backend() != "nccl":
+        print(f"[bench] backend {dist.get_backend()} is not nccl (RCCL): refusing to run", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import enhanced_train
     torch.manual_seed(42)  # reference seeds with set_seed(42) (pretrain.py:13-17); every rank builds the same weights
-    model = enhanced_train.EnhancedCycleGAN(channels=args.channels, num_transformer_blocks=0, device=dev)
-    model.sync_replicas()
-    if args.style_loss:
-        sgen = [torch.Generator().manual_seed(2001 + k) for k in range(3)]
-        refs = [(torch.rand((4, 3, args.size, args.size), generator=g_) * 2 - 1) for g_ in sgen]
-        model.attach_style_loss(refs, (0.5, 0.3, 0.2), lambda_style=1.0)
     gen = torch.Generator().manual_seed(1234 + dp.rank())
     shape = (args.batch, 3, args.size, args.size)
-    real_A = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
-    real_B = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
+
+    if args.kind == "train":
+        import enhanced_train
+        model = enhanced_train.EnhancedCycleGAN(channels=args.channels, num_transformer_blocks=0, device=dev)
+        model.sync_replicas()
+        if args.style_loss:
+            sgen = [torch.Generator().manual_seed(2001 + k) for k in range(3)]
+            refs = [(torch.rand((4, 3, args.size, args.size), generator=g_) * 2 - 1) for g_ in sgen]
+            model.attach_style_loss(refs, (0.5, 0.3, 0.2), lambda_style=1.0)
+        real_A = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
+        real_B = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
+        images_per_step = 2 * args.batch
+
+        def step():
+            return model.train_step_async(real_A, real_B)
+    else:
+        import enhanced_generator
+        from mstg_hip.optim import FlatAdam
+        net = enhanced_generator.EnhancedGenerator(channels=args.channels, num_transformer_blocks=0).to(dev)
+        x = (torch.rand(shape, generator=gen) * 2 - 1).to(dev)
+        images_per_step = args.batch
+        if args.kind == "fwd":
+            net.eval()
+            if args.dtype == "f16":
+                net.half_inference()
+
+            def step():
+                with torch.no_grad():
+                    return net(x).float().abs().mean().reshape(1)
+        else:
+            opt = FlatAdam(net.parameters(), lr=5e-5, betas=(0.5, 0.999))  # flat gradient buffer = what DP all-reduces
+            for b_ in (opt.flat,):
+                dp.broadcast_(b_)
+
+            def step():
+                opt.zero_grad()
+                with ops.direct_param_grads():
+                    loss = net(x).abs().mean()
+                    loss.backward()
+                dp.allreduce_mean_(opt.grad)
+                return loss.detach().reshape(1)
 
     def barrier():
         if world > 1:
@@ -121,11 +277,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        model.train_step_async(real_A, real_B)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = model.train_step_async(real_A, real_B)
+        losses = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -134,13 +290,13 @@ def main():
         dt = float(t.item())
     finite = bool(torch.isfinite(losses).all())
     ms = dt / args.steps * 1e3
-    value = 2.0 * args.batch * world / (dt / args.steps)
+    value = images_per_step * world / (dt / args.steps)
 
     roofline = None
     if not args.no_roofline:
         # EVERY rank runs the instrumented step (it contains the two gradient all-reduces); only rank 0 reports
         ops.KernelTimer.enabled, ops.KernelTimer.records = True, []
-        model.train_step_async(real_A, real_B)
+        step()
         torch.cuda.synchronize()
         ops.KernelTimer.enabled = False
     if not args.no_roofline and dp.rank() == 0:
@@ -151,45 +307,52 @@ def main():
                 print(f"[kernels] {sym:72s} launches {r['launches']:5d}  {r['ms']:9.3f} ms  {100 * r['ms'] / total_ms:5.1f}%  "
                       f"{r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:8.2f} TFLOP/s  {r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0:9.1f} GB/s",
                       file=sys.stderr)
-        # the timer brackets C-ABI calls; a call that launches two kernels (norm_act_fwd / norm_act_bwd = partial + apply) cannot
-        # be attributed per kernel, so the dominant KERNEL is taken among the single-kernel calls (their names are the symbols
-        # rocprofv3 reports); the two-kernel calls stay in --kernel-table
+        # the timer brackets C-ABI calls; a call that launches two kernels cannot be attributed per kernel, so the dominant KERNEL
+        # is taken among the single-kernel calls (their names are the symbols rocprofv3 reports); the others stay in --kernel-table
         sym, r = max(((k, v) for k, v in table.items() if "_kernel" in k), key=lambda kv: kv[1]["ms"])
         sec = r["ms"] / 1e3
-        t_mfma, t_hbm = r["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
+        peak_mfma = PEAK_F16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_F32_MFMA_TFLOPS
+        t_mfma, t_hbm = r["flops"] / (peak_mfma * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
         if t_mfma >= t_hbm:
             ach = r["flops"] / sec / 1e12
-            roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None}
+            roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma, "unit": "TFLOP/s",
+                        "frac": round(ach / peak_mfma, 4), "traffic": None}
         else:
             ach = r["bytes"] / sec / 1e9
             roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
         roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"])
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic(sym, args)
-        # per-launch durations are taken with the step on ONE stream (EnhancedCycleGAN drops its two side streams while
+        # per-launch durations are taken with the step on ONE stream (EnhancedCycleGAN drops its side streams while
         # ops.KernelTimer is enabled): on two streams launches overlap and a launch's event-to-event time includes its neighbour
-        roofline["measured"] = "instrumented step on one stream (MSTG_STREAMS=0 equivalent); timed region runs on two"
+        roofline["measured"] = "instrumented step on one stream (MSTG_STREAMS=0 equivalent)"
         roofline.update({"kernel": sym, "launches_per_step": r["launches"], "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                          "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2)})
+        # whole-step view against both roofs (algorithmic work of every timed launch / wall time of the timed region)
+        tot_fl, tot_by = sum(v["flops"] for v in table.values()), sum(v["bytes"] for v in table.values())
+        roofline["step"] = {"algorithmic_tflop": round(tot_fl / 1e12, 4), "algorithmic_gb": round(tot_by / 1e9, 3),
+                            "tflops_over_wall": round(tot_fl / 1e12 / (ms / 1e3), 2), "gbs_over_wall": round(tot_by / 1e9 / (ms / 1e3), 1)}
 
     cpu = None
     if dp.rank() == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.channels, args.size)
+        cpu = cpu_baseline(args)
 
     if dp.rank() == 0:
-        line = {"metric": "train-step images/sec (fwd+bwd+loss), 256x256 batch32", "value": round(value, 2), "unit": "images/sec",
+        line = {"metric": metric_label(args), "value": round(value, 2), "unit": "images/sec",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"reference CycleGAN train_step (2x EnhancedGenerator + 2x EnhancedDiscriminator, channels={args.channels}, "
-                                       f"num_transformer_blocks=0), {args.batch} image pairs/GPU at {args.size}x{args.size}, fwd+bwd+loss+Adam"
-                                       + (" + build-defined VGG16/Gram multi-style loss (3 refs)" if args.style_loss else ""),
-                           "pairs_per_gpu": args.batch, "images_per_step_per_gpu": 2 * args.batch, "size": args.size,
-                           "channels": args.channels, "parallelism": f"dp{world}", "losses_finite": finite},
+                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": workload_label(args), "baseline_config": args.config,
+                           "per_gpu_batch": args.batch, "images_per_step_per_gpu": images_per_step, "size": args.size,
+                           "channels": args.channels, "parallelism": f"dp{world}",
+                           "collective": (dist.get_backend() if world > 1 else "none"), "losses_finite": finite},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if not finite:
+        print("[bench] non-finite value in the step's outputs", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

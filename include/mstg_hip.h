@@ -39,6 +39,8 @@ extern "C" {
 const char* mstg_version(void);    /* "mstg-hip <semver> gfx950" */
 const char* mstg_arch(void);       /* "gfx950" */
 const char* mstg_last_error(void); /* text of the last failing HIP call on this thread, "" if none */
+/* The MSTG_* environment switches are read when the library is loaded; call this after changing one. */
+void mstg_env_refresh(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Convolutions.  One descriptor describes the MODULE (nn.Conv2d or nn.ConvTranspose2d); the three

@@ -162,6 +162,14 @@ class EnhancedCycleGAN:
         def on(st):
             return torch.cuda.stream(st) if two else _NullCtx()
 
+        def join_backward():
+            """The weight-gradient kernels of a backward run on the side streams of their forwards and write the optimizer's
+            flat gradient buffer directly (ops.direct_param_grads); the all-reduce and the Adam step read that buffer on the
+            main stream.  Ordered here explicitly, not through the autograd engine's end-of-backward stream sync."""
+            if two:
+                for st in side:
+                    main.wait_stream(st)
+
         if self.batch_generator_passes:
             # fake_B = G_AB(real_A) (:63) and idt_B = G_AB(real_B) (:93) use the same weights (the generator optimizer only
             # steps at the end) and every op of the generator is per-sample, so one batched pass gives both, bit for bit
@@ -198,6 +206,7 @@ class EnhancedCycleGAN:
         d_fake_loss = (dA_fake + dB_fake) * 0.5
         d_loss = d_real_loss + d_fake_loss
         d_loss.backward()
+        join_backward()
         dp.allreduce_mean_(self.d_optimizer.grad)
         self.d_optimizer.step()
         # ---- generator update (reference :88-123); D weights take no gradient here (it would be discarded)
@@ -252,6 +261,7 @@ class EnhancedCycleGAN:
         finally:
             for p in self._d_params:
                 p.requires_grad_(True)
+        join_backward()
         dp.allreduce_mean_(self.g_optimizer.grad)
         self.g_optimizer.step()
         out = [d_loss.detach(), g_loss.detach(), cycle_loss.detach(), identity_loss.detach(), structure_loss.detach()]
@@ -266,7 +276,23 @@ class EnhancedCycleGAN:
     def save_models(self, save_dir, epoch):  # reference :133-152
         save_path = Path(save_dir)
         save_path.mkdir(parents=True, exist_ok=True)
-        torch.save({"epoch": epoch, "G_AB_state_dict": self.G_AB.state_dict()}, save_path / f"G_AB_epoch_{epoch}.pth")
-        torch.save({"epoch": epoch, "G_BA_state_dict": self.G_BA.state_dict()}, save_path / f"G_BA_epoch_{epoch}.pth")
-        torch.save({"epoch": epoch, "D_A_state_dict": self.D_A.state_dict(), "D_B_state_dict": self.D_B.state_dict()},
+
+        def sd(m):  # parameters are views of an optimizer's flat buffer: torch.save would serialise the WHOLE buffer per view
+            return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+        torch.save({"epoch": epoch, "G_AB_state_dict": sd(self.G_AB)}, save_path / f"G_AB_epoch_{epoch}.pth")
+        torch.save({"epoch": epoch, "G_BA_state_dict": sd(self.G_BA)}, save_path / f"G_BA_epoch_{epoch}.pth")
+        torch.save({"epoch": epoch, "D_A_state_dict": sd(self.D_A), "D_B_state_dict": sd(self.D_B)},
                    save_path / f"discriminators_epoch_{epoch}.pth")
+
+    def load_models(self, save_dir, epoch):
+        """Inverse of save_models (the reference has no resume path for the GAN trainer; its inference
+        scripts read the same files: advanced_transform.py:14-32).  Strict; values are copied INTO the flat-buffer views."""
+        save_path = Path(save_dir)
+        for fname, pairs in ((f"G_AB_epoch_{epoch}.pth", (("G_AB_state_dict", self.G_AB),)),
+                             (f"G_BA_epoch_{epoch}.pth", (("G_BA_state_dict", self.G_BA),)),
+                             (f"discriminators_epoch_{epoch}.pth", (("D_A_state_dict", self.D_A), ("D_B_state_dict", self.D_B)))):
+            ckpt = torch.load(save_path / fname, map_location=self.device, weights_only=True)
+            for key, module in pairs:
+                module.load_state_dict(ckpt[key], strict=True)
+        return epoch

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mstg_version": (C.c_char_p, []),
     "mstg_arch": (C.c_char_p, []),
     "mstg_last_error": (C.c_char_p, []),
+    "mstg_env_refresh": (None, []),
     "mstg_conv2d_kernel_name": (C.c_char_p, [_dp, _i]),
     "mstg_conv2d_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),

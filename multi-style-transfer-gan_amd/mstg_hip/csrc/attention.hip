@@ -1114,13 +1114,13 @@ static int launch_attn_blk(bool bwd, const float* qkv, const float* d_o, float* 
 }
 
 static bool attn_blk4() {  // MSTG_ATTN_BLK4=0: one wave per window also above 64 channels
-    const char* e = getenv("MSTG_ATTN_BLK4");
+    const char* e = env_get(ENV_ATTN_BLK4);
     return !(e && e[0] == '0');
 }
 static bool attn_blk64() {
     // 32 < C <= 64: the row-blocked kernel needs 26 KB of LDS per wave instead of 43 KB (6 waves per CU instead of 3) and was
     // 1.4x (forward) / 1.65x (backward) faster at 256x256, C = 64; MSTG_ATTN_BLK64=0 selects the whole-matrix kernel
-    const char* e = getenv("MSTG_ATTN_BLK64");
+    const char* e = env_get(ENV_ATTN_BLK64);
     return !(e && e[0] == '0');
 }
 

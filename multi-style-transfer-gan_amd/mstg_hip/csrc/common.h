@@ -28,6 +28,16 @@ inline int fail_arg(int code, const char* what) {
         if (e__ != hipSuccess) return mstg::fail_launch(e__, what); \
     } while (0)
 
+// ---- runtime switches ------------------------------------------------------------------------------------------------
+// The MSTG_* environment switches are read ONCE, when the library is loaded, and again on
+// mstg_env_refresh(): a train step makes ~1400 launches and each planner used to call getenv() several times per launch.
+enum EnvKnob {
+    ENV_ATTN_BLK4, ENV_ATTN_BLK64, ENV_WGRAD_1X1, ENV_WGRAD_TS_MAXCH, ENV_WGRAD_PLAIN, ENV_WGRAD_OLD, ENV_NO_DPACK, ENV_IGEMM,
+    ENV_STREAM, ENV_PF, ENV_WGLOB, ENV_HEAVY_PER_CU, ENV_DBG, ENV_DBG_LDS_KB, ENV_MS_WGRAD_PACKED, ENV_MS_FWD4, ENV_NO_PACK_CACHE,
+    ENV_COUNT
+};
+const char* env_get(EnvKnob k);  // value as of the last refresh, nullptr when unset (runtime.hip)
+
 constexpr int WAVE = 64;
 
 // fp32-in / fp32-accumulate MFMA, 16x16 tile, K = 4 per instruction (v_mfma_f32_16x16x4_f32).

@@ -15,7 +15,6 @@
 #include <stdlib.h>
 
 namespace mstg {
-thread_local char g_last_error[256] = "";
 
 struct IGemmArgs {
     const float* x;
@@ -887,7 +886,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     // <= 4 output channels (the RGB head, the stem's input gradient, the discriminator heads, 4-channel branches): pack four
     // horizontally adjacent taps into the 16 filter rows of the MFMA tile instead of padding 4 channels to 16
     a.dpack = !a.phase && a.Co <= 4 && a.stride == 1 && a.dil == 1 && a.KW > 1;
-    { const char* e = getenv("MSTG_NO_DPACK"); if (e && e[0] == '1') a.dpack = 0; }
+    { const char* e = env_get(ENV_NO_DPACK); if (e && e[0] == '1') a.dpack = 0; }
     igemm_geometry(a, TILE_H);
     p.pf = 2;
     p.stream = 0;
@@ -924,7 +923,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     // measured on MI355X: with the packed filter the high-occupancy kernel wins everywhere except on deep-channel layers
     // with few tiles (the discriminator's 32x32 / 16x16 maps), where a workgroup has too few neighbours to hide behind
     {
-        const char* e = getenv("MSTG_IGEMM");
+        const char* e = env_get(ENV_IGEMM);
         if (!(e && e[0] == 'h')) p.heavy = p.heavy && a.Cr >= 64 && a.N * a.tiles_x * a.tiles_y * (p.CoP / p.BN) <= 1024;
         if (e && e[0] == 'l') p.heavy = 0;
     }
@@ -936,14 +935,14 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
         //      LDS (<= 28 KiB), the patch within SNB slots per thread, >= 3 workgroups per CU ---------------------------------
         p.stream = 0;
         {
-            const char* e = getenv("MSTG_STREAM");
+            const char* e = env_get(ENV_STREAM);
             // Off by default: measured on MI355X (tools/diag_stamps.py) it wins only on the tap-heavy 16-channel layers
             // (3x3 dilation 4: 0.165 -> 0.140 ms, 7x7 head: 0.278 -> 0.245 ms) and loses on the rest, because those layers are
             // bound by the L2 -> CU traffic of the halo re-reads, not by the serialised phases.  MSTG_STREAM=1 enables it.
             const bool allow = (e && e[0] == '1') && (p.src == 0 || (p.src == 2 && p.V == 1));
             const size_t wsz = (size_t)p.nchunks * a.ntaps * p.BN * p.CKP;
             const int ny = p.CoP / p.BN;
-            const char* epf = getenv("MSTG_PF");
+            const char* epf = env_get(ENV_PF);
             const int force = epf ? atoi(epf) : 0;
             for (int th = 16; allow && th >= 8 && !p.stream; th -= 8) {
                 if ((th == 16 && force == 2) || (th == 8 && force == 4)) continue;
@@ -967,10 +966,10 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
         if (p.stream) return MSTG_OK;
         // four rows per wave where the taller patch still leaves >= 3 workgroups per CU and the grid stays >= 4 per CU
         {
-            const char* e = getenv("MSTG_PF");
+            const char* e = env_get(ENV_PF);
             const int force = e ? atoi(e) : 0;
             const int ph16 = a.phase ? 18 : (a.dpack ? 15 + a.KH : 15 * a.stride + (a.KH - 1) * a.dil + 1);
-            const char* ew = getenv("MSTG_WGLOB");
+            const char* ew = env_get(ENV_WGLOB);
             const int wg16 = ew ? atoi(ew) : (p.V == 4 ? 1 : 0);
             const size_t lds16 = ((size_t)((ph16 * a.PW * p.CKP + 3) & ~3) + (wg16 ? 0 : (size_t)tg * p.BN * p.CKP) + 64) * sizeof(float);
             const long blocks16 = (long)a.N * a.tiles_x * cdiv(a.Gh, 16) * (p.CoP / p.BN) * p.ncls;
@@ -984,7 +983,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
         {
             // filter fragments from L2 where a tap's MFMAs (V * NFW * PF of them) are long enough to cover the fetch of the tap
             // after next: frees the LDS of the filter slice (more workgroups per CU) and its staging barrier
-            const char* e = getenv("MSTG_WGLOB");
+            const char* e = env_get(ENV_WGLOB);
             a.wglob = e ? atoi(e) : (p.V == 4 ? 1 : 0);
         }
         p.lds = (patch_floats_l + (a.wglob ? 0 : (size_t)tg * p.BN * p.CKP) + 64) * sizeof(float);  // + tap-offset table (<= 64 taps)
@@ -1045,7 +1044,7 @@ static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
     // workgroup's tiles all fall into one XCD's contiguous run of the tile order (xcd_swizzle)
     const int ntiles = a.N * a.tiles_x * a.tiles_y, ny = p.CoP / p.BN, nz = p.ncls;
     int per_cu = p.lds <= 80 * 1024 ? 2 : 1;
-    { const char* e = getenv("MSTG_HEAVY_PER_CU"); if (e) per_cu = atoi(e); }
+    { const char* e = env_get(ENV_HEAVY_PER_CU); if (e) per_cu = atoi(e); }
     int gx = (256 * per_cu) / (ny * nz);
     gx = gx < 8 ? 8 : (gx & ~7);
     if (gx > ntiles) gx = ntiles;
@@ -1065,8 +1064,8 @@ int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStrea
     a.dbg = 0;
     IGemmPlan p;
     if (int rc = plan_igemm(a, p)) return rc;
-    { const char* e = getenv("MSTG_DBG"); if (e) a.dbg = atoi(e); }                       // experiments only: bit 0 = one tap only
-    { const char* e = getenv("MSTG_DBG_LDS_KB"); if (e && !p.heavy) p.lds += (size_t)atoi(e) * 1024; }  // lower the occupancy
+    { const char* e = env_get(ENV_DBG); if (e) a.dbg = atoi(e); }                       // experiments only: bit 0 = one tap only
+    { const char* e = env_get(ENV_DBG_LDS_KB); if (e && !p.heavy) p.lds += (size_t)atoi(e) * 1024; }  // lower the occupancy
     if (!workspace || workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv: workspace too small for the packed filter");
     float* wp = (float*)workspace;
     if (int rc = launch_pack(a, p, wp, st)) return rc;
@@ -1207,6 +1206,3 @@ extern "C" int mstg_debug_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mstg::g_dbg_stamps), sizeof(unsigned long long) * 64 * 8);
 }
 #endif
-extern "C" const char* mstg_version(void) { return "mstg-hip 0.1.0 gfx950"; }
-extern "C" const char* mstg_arch(void) { return "gfx950"; }
-extern "C" const char* mstg_last_error(void) { return mstg::g_last_error; }

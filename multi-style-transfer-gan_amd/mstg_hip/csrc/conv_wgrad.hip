@@ -550,7 +550,7 @@ static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st) {
 
 // eligible: 1x1, stride 1, both tensors NHWC with 16-byte aligned channel slices, <= 64 input and <= 192 output channels
 static bool wgrad_1x1_ok(const WGradArgs& a) {
-    const char* e = getenv("MSTG_WGRAD_1X1");
+    const char* e = env_get(ENV_WGRAD_1X1);
     if (e && e[0] == '0') return false;
     return a.T == 1 && a.stride == 1 && !a.g_nchw && !a.h_nchw && ((a.g_ctot | a.g_coff | a.Cg | a.h_ctot | a.h_coff | a.Ch) & 3) == 0 &&
            a.Cg * a.Ch >= 256;
@@ -673,7 +673,7 @@ static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
 }
 
 static int wgrad_ts_max_ch() {
-    const char* e = getenv("MSTG_WGRAD_TS_MAXCH");
+    const char* e = env_get(ENV_WGRAD_TS_MAXCH);
     return e ? atoi(e) : 128;  // measured: 8-18 % faster than the pixel-split kernel up to 128 grid channels (two fragments per workgroup)
 }
 
@@ -741,7 +741,7 @@ static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float*
     a.mode = MODE_PLAIN;
     if (a.Cg <= 4 && a.dil == 1 && a.KW > 1) a.mode = MODE_PACKX;
     else if (a.Ch <= 4 && a.dil == 1 && a.stride == 1 && a.KW > 1) a.mode = MODE_DPACK;
-    { const char* e = getenv("MSTG_WGRAD_PLAIN"); if (e && e[0] == '1') a.mode = MODE_PLAIN; }
+    { const char* e = env_get(ENV_WGRAD_PLAIN); if (e && e[0] == '1') a.mode = MODE_PLAIN; }
     a.tapsx = cdiv(a.KW, 4);
     a.xshift = a.mode == MODE_DPACK ? 3 : 0;
     a.htw = a.mode == MODE_DPACK ? 20 : 16;
@@ -833,7 +833,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
                 MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
             }
         return MSTG_OK;
-    } else if (use_ts && !(getenv("MSTG_WGRAD_OLD") && getenv("MSTG_WGRAD_OLD")[0] == '1')) {
+    } else if (use_ts && !(env_get(ENV_WGRAD_OLD) && env_get(ENV_WGRAD_OLD)[0] == '1')) {
         const TsPlan p = plan_ts(a);
         if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
         int rc = p.UW == 4 ? launch_ts_t<4>(a, p, st) : (p.UW == 8 ? launch_ts_t<8>(a, p, st) : launch_ts_t<16>(a, p, st));

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void wgrad_msp_reduce_kernel(const float* __re
 
 template <int CH>
 static bool ms_wgrad_packed() {
-    const char* e = getenv("MSTG_MS_WGRAD_PACKED");
+    const char* e = env_get(ENV_MS_WGRAD_PACKED);
     return CH <= 32 && !(e && e[0] == '0');
 }
 
@@ -691,7 +691,7 @@ template <int CH>
 static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
     typedef MsUnits<CH> G;
     {
-        const char* e = getenv("MSTG_MS_FWD4");
+        const char* e = env_get(ENV_MS_FWD4);
         bool aligned = true;
         for (int k = 0; k < 4; ++k) aligned = aligned && (reinterpret_cast<uintptr_t>(prm.b[k]) & 15) == 0;
         const bool use4 = CH == 16 || (CH == 32 && e && e[0] == '2');

@@ -23,6 +23,11 @@ Tensor = torch.Tensor
 # ----------------------------------------------------------------------------------------------------------
 # plumbing
 # ----------------------------------------------------------------------------------------------------------
+def refresh_env() -> None:
+    """Make the library re-read the MSTG_* switches (it reads them once, at load).  Python-side switches are read per call."""
+    _lib.load().mstg_env_refresh()
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -204,7 +209,9 @@ class ConvFn(torch.autograd.Function):
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
         conv_fwd_raw(d, x, w, b, y)
         ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
-        ctx.prefs = (w, b)  # the objects handed to apply(): nn.Parameters when the layer owns them (see _grad_slot)
+        # the objects handed to apply() are nn.Parameters when the layer owns them; only their .grad slots are looked up through
+        # these references in backward (see _grad_slot) -- the VALUES used there come from saved_tensors (version-checked)
+        ctx.prefs = (w, b)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
 

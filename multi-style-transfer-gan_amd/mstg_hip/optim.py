@@ -52,8 +52,22 @@ class FlatAdam:
         self.grad.zero_()
         self._attach_grads()
 
+    def check_views(self):
+        """Every parameter and its gradient must still be the views into the flat buffers this optimizer created: a later
+        ``module.half()`` / ``.to(device)`` / ``module.zero_grad(set_to_none=True)`` silently re-homes them, after which the fused
+        step would update stale copies."""
+        base_p, base_g = self.flat.data_ptr(), self.grad.data_ptr()
+        for p, o in zip(self.params, self.offsets):
+            if p.data_ptr() != base_p + 4 * o:
+                raise RuntimeError("FlatAdam: a parameter no longer lives in the optimizer's flat buffer (was the module moved or "
+                                   "cast after the optimizer was built?)")
+            if p.grad is None or p.grad.data_ptr() != base_g + 4 * o:
+                raise RuntimeError("FlatAdam: a parameter's .grad is not the optimizer's flat-gradient view; use "
+                                   "optimizer.zero_grad(), not module.zero_grad(set_to_none=True)")
+
     @torch.no_grad()
     def step(self):
+        self.check_views()
         g = self.param_groups[0]
         self.step_count += 1
         ops.adam_step_flat(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0], g["betas"][1], g["eps"],

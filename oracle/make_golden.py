@@ -339,6 +339,156 @@ def gen_train_step(eg, et):
     np.savez_compressed(os.path.join(GOLD, "train_step_c8_64x64.npz"), **out)
 
 
+def assemble_reference_cyclegan(eg, et, C, sds, dtype):
+    """An ``EnhancedCycleGAN`` of the reference built without its ctor (which hard-codes num_transformer_blocks=1,
+    enhanced_train.py:18-19, and therefore needs the missing module): same attributes, hyper-parameters of :36-57."""
+    import itertools
+    self = et.EnhancedCycleGAN.__new__(et.EnhancedCycleGAN)
+    self.device = torch.device("cpu")
+    self.G_AB = eg.EnhancedGenerator(channels=C, num_transformer_blocks=0)
+    self.G_BA = eg.EnhancedGenerator(channels=C, num_transformer_blocks=0)
+    self.D_A = eg.EnhancedDiscriminator(channels=C)
+    self.D_B = eg.EnhancedDiscriminator(channels=C)
+    for m, sd in zip((self.G_AB, self.G_BA, self.D_A, self.D_B), sds):
+        m.load_state_dict(sd)
+        m.to(dtype)
+    self.G_AB.gradient_checkpointing_enable()
+    self.G_BA.gradient_checkpointing_enable()
+    self.g_optimizer = torch.optim.Adam(itertools.chain(self.G_AB.parameters(), self.G_BA.parameters()), lr=5e-5, betas=(0.5, 0.999))
+    self.d_optimizer = torch.optim.Adam(itertools.chain(self.D_A.parameters(), self.D_B.parameters()), lr=2e-4, betas=(0.5, 0.999))
+    self.scaler = torch.cuda.amp.GradScaler()
+    self.criterion_gan = torch.nn.MSELoss()
+    self.criterion_cycle = torch.nn.L1Loss()
+    self.criterion_identity = torch.nn.L1Loss()
+    self.criterion_structure = torch.nn.L1Loss()
+    self.lambda_cycle, self.lambda_identity, self.lambda_structure = 10.0, 2.0, 0.5
+    self.captured = {}
+
+    def hook(name):
+        def h(opt, args, kwargs):  # gradients as the optimizer sees them, right before its step
+            self.captured[name] = [None if p.grad is None else p.grad.detach().clone() for g in opt.param_groups for p in g["params"]]
+        return h
+
+    self.d_optimizer.register_step_pre_hook(hook("d"))
+    self.g_optimizer.register_step_pre_hook(hook("g"))
+    return self
+
+
+LOSS_KEYS = ("d_loss", "g_loss", "cycle_loss", "identity_loss", "structure_loss")
+
+
+def _force_state(dst, src, dtype):
+    """Teacher forcing: copy models (parameters + spectral-norm u/v buffers) and both optimizers' states from ``src``."""
+    for name in ("G_AB", "G_BA", "D_A", "D_B"):
+        getattr(dst, name).load_state_dict({k: v.to(dtype) for k, v in getattr(src, name).state_dict().items()})
+    for name in ("g_optimizer", "d_optimizer"):
+        sd = getattr(src, name).state_dict()
+        st = {i: {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() and k != "step" else (v.clone() if torch.is_tensor(v) else v))
+                  for k, v in s.items()} for i, s in sd["state"].items()}
+        getattr(dst, name).load_state_dict({"state": st, "param_groups": sd["param_groups"]})
+
+
+def _tensor_dists(g32, g64):
+    out = []
+    for a, b in zip(g32, g64):
+        if b is None:
+            out.append(-1.0)
+        else:
+            out.append(float((a.double() - b).norm() / b.norm().clamp_min(1e-300)))
+    return out
+
+
+def _agg_dist(g32, g64, live):
+    num = sum(float((a.double() - b).pow(2).sum()) for a, b, lv in zip(g32, g64, live) if lv)
+    den = sum(float(b.pow(2).sum()) for b, lv in zip(g64, live) if lv)
+    return (num / max(den, 1e-300)) ** 0.5
+
+
+def run_forced(eg, et, C, shape, seeds, in_seed, steps=3):
+    """Reference train_step for ``steps`` steps in fp64 (free running) and, beside it, in fp32 TEACHER-FORCED: before each
+    step the fp32 instance receives the fp64 instance's models and optimizer states, so each fp32 step is the same function
+    as the fp64 step evaluated in single precision.  Returns per step: fp64 losses / gradients, the fp32 run's distances
+    from them, and the state (spectral-norm vectors) the step started from."""
+    sds = [R.make_state_dict(R.generator_spec(C), seeds[0]), R.make_state_dict(R.generator_spec(C), seeds[1]),
+           R.make_state_dict(R.discriminator_spec(C), seeds[2]), R.make_state_dict(R.discriminator_spec(C), seeds[3])]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r64 = assemble_reference_cyclegan(eg, et, C, sds, torch.float64)
+        r32 = assemble_reference_cyclegan(eg, et, C, sds, torch.float32)
+        g_names = [k for m in (r64.G_AB, r64.G_BA) for k, _ in m.named_parameters()]
+        d_names = [k for m in (r64.D_A, r64.D_B) for k, _ in m.named_parameters()]
+        rec = []
+        for step in range(steps):
+            a = R.make_input(shape, in_seed + 2 * step)
+            b = R.make_input(shape, in_seed + 1 + 2 * step)
+            _force_state(r32, r64, torch.float32)
+            uv = {f"{dn}.{k}": v.detach().clone() for dn, D in (("D_A", r64.D_A), ("D_B", r64.D_B)) for k, v in D.state_dict().items()
+                  if k.endswith(("_u", "_v"))}
+            l32 = r32.train_step(a, b)
+            l64 = r64.train_step(a.double(), b.double())
+            g64, d64, g32, d32 = r64.captured["g"], r64.captured["d"], r32.captured["g"], r32.captured["d"]
+            live_g = [x is not None and not R_dead_bias(n) for n, x in zip(g_names, g64)]
+            live_d = [x is not None and not R_dead_bias(n) for n, x in zip(d_names, d64)]
+            rec.append({"l64": l64, "l32": l32, "g64": g64, "d64": d64, "uv": uv,
+                        "g32_dist": _tensor_dists(g32, g64), "d32_dist": _tensor_dists(d32, d64),
+                        "g32_agg": _agg_dist(g32, g64, live_g), "d32_agg": _agg_dist(d32, d64, live_d)})
+    return sds, g_names, d_names, rec
+
+
+def R_dead_bias(name: str) -> bool:
+    """Bias of a convolution feeding an InstanceNorm: exactly-zero gradient in exact arithmetic (the norm removes the mean)."""
+    if not name.endswith(".bias"):
+        return False
+    stem = name[:-5]
+    return (stem == "initial.0" or stem.endswith((".branch1.0", ".branch2.0", ".branch3.0", ".branch4.0", ".fusion.0"))
+            or stem in ("down1.0", "down2.0", "up1.0", "up2.0", "main.2", "main.5", "main.8", "structure_head.0"))
+
+
+def gen_train_step_fp64(eg, et):
+    """Multi-step pin of the train step in fp64.  The reference's own fp32 gradients sit 1e-2 (step 0) to
+    several 1e-1 (steps 1-2) from its fp64 gradients on a free-running trajectory: Adam's first updates are lr*sign(g), so
+    every element whose gradient sign is rounding noise moves 2*lr apart between two correct implementations, and two chained
+    generators (50 un-affine InstanceNorm+ReLU) turn that into ReLU-mask flips.  No seed/size makes steps 1-2 well conditioned
+    (free-running scan over 160 draws: best 8e-3 / 6e-2 at steps 1 / 2).  What IS well conditioned is each step as a function of its starting
+    state.  So the fixture holds, for 3 steps of the reference's unmodified train_step run in fp64: the five losses, every
+    gradient both optimizers see, the spectral-norm vectors each step starts from -- and, per step and tensor, how far the
+    reference's own fp32 evaluation of THE SAME step (teacher-forced to the fp64 state) is from the fp64 result.  The GPU test
+    teacher-forces the HIP build the same way (parameters and Adam moments re-derived in fp64 from the stored gradients) and
+    holds it to  max(1e-3, 1.5 x the reference's own fp32 distance)  per step, per loss and per live gradient tensor."""
+    C = 8
+    # candidates: the two draws of an 80-seed scan at 32x32 (seeds 300..616) whose three forced steps are all under 1e-3, one
+    # typical draw per size for the record (they print how ill-conditioned the usual case is)
+    cands = [((2, 3, 32, 32), s0) for s0 in (388, 512, 144)] + [((2, 3, 48, 48), 244), ((2, 3, 64, 64), 132)]
+    best = None
+    for shape, s0 in cands:
+        seeds, ins = (s0, s0 + 1, s0 + 2, s0 + 3), 1000 + s0
+        sds, g_names, d_names, rec = run_forced(eg, et, C, shape, seeds, ins)
+        score = max(max(r["g32_agg"], r["d32_agg"]) for r in rec)
+        print(f"  fp64 pin candidate {shape} seeds {seeds}: reference-fp32 forced distance per step "
+              f"{[(round(r['d32_agg'], 6), round(r['g32_agg'], 6)) for r in rec]}")
+        if best is None or score < best[0]:
+            best = (score, shape, seeds, ins, sds, g_names, d_names, rec)
+    score, shape, seeds, ins, sds, g_names, d_names, rec = best
+    print(f"  chosen: {shape} seeds {seeds} input seed {ins}: worst forced reference-fp32 distance {score:.2e}")
+    out = {"C": C, "shape": np.array(shape), "seeds": np.array(seeds), "in_seed": ins, "steps": len(rec),
+           "g_names": np.array(g_names), "d_names": np.array(d_names)}
+    for k, r in enumerate(rec):
+        out[f"losses64_{k}"] = np.array([r["l64"][key] for key in LOSS_KEYS], dtype=np.float64)
+        out[f"losses32_{k}"] = np.array([r["l32"][key] for key in LOSS_KEYS], dtype=np.float64)
+        out[f"g32_dist_{k}"] = np.array(r["g32_dist"], dtype=np.float64)
+        out[f"d32_dist_{k}"] = np.array(r["d32_dist"], dtype=np.float64)
+        out[f"g32_agg_{k}"], out[f"d32_agg_{k}"] = r["g32_agg"], r["d32_agg"]
+        for i, g in enumerate(r["g64"]):
+            if g is not None:
+                out[f"g64_{k}_{i}"] = g.to(torch.float32).numpy()
+        for i, g in enumerate(r["d64"]):
+            if g is not None:
+                out[f"d64_{k}_{i}"] = g.to(torch.float32).numpy()
+        for name, v in r["uv"].items():
+            out[f"uv_{k}_{name}"] = v.to(torch.float32).numpy()
+    np.savez_compressed(os.path.join(GOLD, "train_step_fp64_c8.npz"), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -350,6 +500,7 @@ def main():
     gen_discriminator(eg)
     gen_plain_generator(pt)
     gen_train_step(eg, et)
+    gen_train_step_fp64(eg, et)
     with open(os.path.join(GOLD, "PROVENANCE.txt"), "w") as f:
         f.write(f"generated by oracle/make_golden.py from {REF} with torch {torch.__version__}, "
                 f"{torch.get_num_threads()} threads, fp32 CPU; weights/inputs: oracle.restatement.make_state_dict/make_input\n")

@@ -25,3 +25,31 @@ def rel_l2(a, b):
     import torch
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _fresh_library_switches(request, monkeypatch):
+    """libmstg_hip.so reads the MSTG_* switches once per load; a test that sets one through ``setenv_refresh`` (or plain
+    monkeypatch + ops.refresh_env()) must not leak it into the next test: re-read after every gpu test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        monkeypatch.undo()
+        from mstg_hip import _lib
+        if _lib._lib is not None:
+            _lib._lib.mstg_env_refresh()
+
+
+@pytest.fixture
+def setenv_refresh(monkeypatch):
+    """setenv/delenv that the HIP library sees at once."""
+    from mstg_hip import ops
+
+    class _S:
+        def set(self, k, v):
+            monkeypatch.setenv(k, v)
+            ops.refresh_env()
+
+        def unset(self, k):
+            monkeypatch.delenv(k, raising=False)
+            ops.refresh_env()
+    return _S()

@@ -1,0 +1,191 @@
+"""The five BASELINE.json workloads at their real spatial sizes (256x256, 512x512, 1024x1024) through the HIP path, once each:
+oracle comparisons where the CPU oracle finishes in seconds (batch 1-2), and size-independent properties at the full batch
+(per-sample independence of the network, linearity of batch-mean gradients, finiteness, determinism).  These are the cases with
+more than 2^16 tiles per launch, tensors beyond 4 GiB and image strides near the 32-bit limits of the staging helpers."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mstg_hip import _lib
+    _lib.load()
+
+
+def report(name, err, tol):
+    print(f"  [parity] {name:64s} rel-L2 {err:.2e} (tol {tol:.0e})")
+    assert err <= tol, f"{name}: {err:.3e} > {tol:.0e}"
+
+
+def _generator(C, seed):
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    sd = R.make_state_dict(R.generator_spec(C), seed)
+    m = eg.EnhancedGenerator(channels=C, num_transformer_blocks=0)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+def test_config1_forward_256_vs_oracle():
+    """BASELINE config #1: one 256x256 image through EnhancedGenerator.forward (direct_transform.py:44-79), every tap."""
+    from oracle import restatement as R
+    m, sd = _generator(16, 301)
+    m.eval()
+    x = R.make_input((1, 3, 256, 256), 302)
+    taps, rt = {}, {}
+    with torch.no_grad():
+        y = m.forward_taps(x.to(DEV), taps)
+        yr = R.generator_forward(sd, x, rt)
+    for k in ("initial", "down1", "down2", "up1", "up2"):
+        report(f"config1 256x256 tap {k}", rel_l2(taps[k].permute(0, 3, 1, 2), rt[k]), 1e-4)
+    report("config1 256x256 pre_tanh", rel_l2(taps["pre_tanh"], rt["pre_tanh"]), 1e-4)
+    report("config1 256x256 out", rel_l2(y, yr), 1e-4)
+
+
+def test_config2_fwd_bwd_batch16_256():
+    """BASELINE config #2: generator forward+backward, batch 16 at 256x256.  (a) oracle: forward and weight gradients of the first
+    two samples (CPU autograd, fp32); (b) per-sample independence: sample i of the batch-16 forward == the batch-1 forward;
+    (c) linearity: the batch-16 gradient of mean|y| is the mean of the two batch-8 halves' gradients."""
+    from oracle import restatement as R
+    m, sd = _generator(16, 311)
+    x = R.make_input((16, 3, 256, 256), 312)
+    xg = x.to(DEV)
+    names = [k for k, _ in m.named_parameters() if not k.startswith("style_encoder")]
+    params = [p for k, p in m.named_parameters() if not k.startswith("style_encoder")]
+
+    def grads_of(inp):
+        y = m(inp)
+        return y.detach(), torch.autograd.grad(y.abs().mean(), params)
+
+    y16, g16 = grads_of(xg)
+    assert torch.isfinite(y16).all() and all(torch.isfinite(g).all() for g in g16)
+    with torch.no_grad():
+        y1 = m(xg[5:6])
+    report("config2 sample 5 of batch 16 vs batch 1", rel_l2(y16[5:6], y1), 1e-6)
+    _, ga = grads_of(xg[:8])
+    _, gb = grads_of(xg[8:])
+    num = sum(float((g - 0.5 * (a + b)).double().pow(2).sum()) for g, a, b in zip(g16, ga, gb))
+    den = sum(float(g.double().pow(2).sum()) for g in g16)
+    report("config2 grad(batch 16) vs mean of the two batch-8 halves", (num / den) ** 0.5, 1e-5)
+    # oracle on two samples
+    y2, g2 = grads_of(xg[:2])
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    yr = R.generator_forward(sdr, x[:2])
+    gr = torch.autograd.grad(yr.abs().mean(), [sdr[k] for k in names])
+    report("config2 256x256 batch-2 forward vs oracle", rel_l2(y2, yr), 1e-4)
+    live = [i for i, n in enumerate(names) if n.endswith("weight")]
+    num = sum(float((g2[i].cpu().double() - gr[i].double()).pow(2).sum()) for i in live)
+    den = sum(float(gr[i].double().pow(2).sum()) for i in live)
+    # fp32 conditioning of this network at 256x256: two correct fp32 implementations differ by ReLU-mask flips
+    report("config2 256x256 batch-2 weight gradients vs oracle (aggregate)", (num / den) ** 0.5, 5e-3)
+
+
+def test_config3_train_step_256():
+    """BASELINE config #3: the CycleGAN train step at 256x256.  Batch 1 against the oracle's train step (five losses); batch 32
+    (the benchmarked shape): finite losses, and the generator-only losses (cycle, identity -- no discriminator, so no
+    spectral-norm state) equal the mean over four batch-8 chunks evaluated with the same weights."""
+    import enhanced_train
+    from oracle import restatement as R
+    C = 16
+    sds = [R.make_state_dict(R.generator_spec(C), 321), R.make_state_dict(R.generator_spec(C), 322),
+           R.make_state_dict(R.discriminator_spec(C), 323), R.make_state_dict(R.discriminator_spec(C), 324)]
+
+    def build():
+        model = enhanced_train.EnhancedCycleGAN(channels=C, num_transformer_blocks=0, device=torch.device(DEV))
+        for mod, sd in zip((model.G_AB, model.G_BA, model.D_A, model.D_B), sds):
+            mod.load_state_dict(sd)
+        return model
+
+    a1, b1 = R.make_input((1, 3, 256, 256), 325), R.make_input((1, 3, 256, 256), 326)
+    ours = build().train_step(a1.to(DEV), b1.to(DEV))
+    ref = R.CycleGANOracle(*[{k: v.clone() for k, v in sd.items()} for sd in sds]).train_step(a1, b1)
+    for k in ref:
+        err = abs(ours[k] - ref[k]) / max(1.0, abs(ref[k]))
+        print(f"  [parity] config3 256x256 batch 1 {k:16s} hip {ours[k]:.6f} oracle {ref[k]:.6f} rel {err:.1e}")
+        assert err <= 1e-4, (k, ours[k], ref[k])
+    g = torch.Generator().manual_seed(327)
+    A = (torch.rand((32, 3, 256, 256), generator=g) * 2 - 1).to(DEV)
+    B = (torch.rand((32, 3, 256, 256), generator=g) * 2 - 1).to(DEV)
+    model = build()
+    model.g_optimizer.param_groups[0]["lr"] = 0.0
+    model.d_optimizer.param_groups[0]["lr"] = 0.0
+    full = model.train_step(A, B)
+    assert all(np.isfinite(v) for v in full.values()), full
+    chunks = [model.train_step(A[i:i + 8], B[i:i + 8]) for i in range(0, 32, 8)]
+    for k in ("cycle_loss", "identity_loss"):
+        mean = sum(c[k] for c in chunks) / 4
+        assert abs(full[k] - mean) <= 1e-5 * abs(mean), (k, full[k], mean)
+    full2 = model.train_step(A, B)  # lr = 0: same weights; only spectral-norm vectors moved on -> generator losses bit-identical
+    assert full2["cycle_loss"] == full["cycle_loss"] and full2["identity_loss"] == full["identity_loss"]
+
+
+def test_config4_multistyle_train_step_512():
+    """BASELINE config #4 shape: 512x512 train step with the build-defined multi-style loss (3 weighted references).  Batch 1
+    against the oracle (six losses; VGG stack at 1/4 width to keep the CPU side in seconds); then the full-width stack at batch
+    2: finite and reproducible."""
+    import enhanced_train
+    from oracle import restatement as R
+    C, shape = 16, (1, 3, 512, 512)
+    sds = [R.make_state_dict(R.generator_spec(C), 331), R.make_state_dict(R.generator_spec(C), 332),
+           R.make_state_dict(R.discriminator_spec(C), 333), R.make_state_dict(R.discriminator_spec(C), 334)]
+    model = enhanced_train.EnhancedCycleGAN(channels=C, num_transformer_blocks=0, device=torch.device(DEV))
+    for mod, sd in zip((model.G_AB, model.G_BA, model.D_A, model.D_B), sds):
+        mod.load_state_dict(sd)
+    refs = [R.make_input(shape, 335 + k) for k in range(3)]
+    model.attach_style_loss(refs, (0.5, 0.3, 0.2), lambda_style=1.0, width_div=4)
+    vgg_sd = {k: v.detach().cpu().clone() for k, v in model.style_loss.features.state_dict().items()}
+    a, b = R.make_input(shape, 338), R.make_input(shape, 339)
+    ours = model.train_step(a.to(DEV), b.to(DEV))
+    oracle = R.CycleGANOracle(*[{k: v.clone() for k, v in sd.items()} for sd in sds])
+    with torch.no_grad():
+        sty = float(R.multi_style_gram_loss(vgg_sd, R.generator_forward(oracle.G_BA, b), refs, [0.5, 0.3, 0.2]))
+    ref = oracle.train_step(a, b)  # the reference's five losses do not depend on the extra term
+    ref["style_loss"] = sty
+    for k in ref:
+        err = abs(ours[k] - ref[k]) / max(1.0, abs(ref[k]))
+        print(f"  [parity] config4 512x512 batch 1 {k:16s} hip {ours[k]:.6f} oracle {ref[k]:.6f} rel {err:.1e}")
+        assert err <= 1e-3, (k, ours[k], ref[k])
+    # full-width VGG stack, batch 2
+    outs = []
+    for _ in range(2):
+        m2 = enhanced_train.EnhancedCycleGAN(channels=C, num_transformer_blocks=0, device=torch.device(DEV))
+        for mod, sd in zip((m2.G_AB, m2.G_BA, m2.D_A, m2.D_B), sds):
+            mod.load_state_dict(sd)
+        g = torch.Generator().manual_seed(340)
+        m2.attach_style_loss([(torch.rand((2, 3, 512, 512), generator=g) * 2 - 1) for _ in range(3)], (0.5, 0.3, 0.2), 1.0)
+        A = (torch.rand((2, 3, 512, 512), generator=g) * 2 - 1).to(DEV)
+        B = (torch.rand((2, 3, 512, 512), generator=g) * 2 - 1).to(DEV)
+        outs.append(m2.train_step(A, B))
+    assert all(np.isfinite(v) for v in outs[0].values()), outs[0]
+    assert outs[0] == outs[1], (outs[0], outs[1])
+
+
+def test_config5_forward_1024_fp32():
+    """BASELINE config #5 shape in fp32 (the parity-path arithmetic): 1024x1024 forward.  Batch 1 against the oracle; batch 64
+    (activations of 4.3 GB: element offsets beyond 2^32 bytes, 65536+ tiles per launch): samples 0 and 63 equal the batch-1
+    result of the same images."""
+    from oracle import restatement as R
+    m, sd = _generator(16, 351)
+    m.eval()
+    x1 = R.make_input((1, 3, 1024, 1024), 352)
+    with torch.no_grad():
+        y1 = m(x1.to(DEV))
+        yr = R.generator_forward(sd, x1)
+    report("config5 1024x1024 batch 1 forward vs oracle", rel_l2(y1, yr), 1e-4)
+    g = torch.Generator().manual_seed(353)
+    x = (torch.rand((64, 3, 1024, 1024), generator=g) * 2 - 1)
+    x[0], x[63] = x1[0], x1[0].flip(-1)
+    with torch.no_grad():
+        y = m(x.to(DEV))
+        y63 = m(x[63:64].to(DEV))
+    assert torch.isfinite(y).all()
+    report("config5 sample 0 of batch 64 vs batch 1", rel_l2(y[0:1], y1), 1e-6)
+    report("config5 sample 63 of batch 64 vs batch 1", rel_l2(y[63:64], y63), 1e-6)

@@ -146,10 +146,13 @@ def test_generator_default_width_vs_oracle(monkeypatch):
     # With the forward through the one-wave attention core (whose activations happen to flip no mask against fp64 for this
     # seed) the default backward kernels meet the strict bar on their own: the looser clause above is about conditioning,
     # not about the four-wave backward.  The switch is read per call, so it can differ between the two passes.
+    from mstg_hip import ops
     monkeypatch.setenv("MSTG_ATTN_BLK4", "0")
+    ops.refresh_env()
     xg2 = x.to(DEV).requires_grad_(True)
     y2 = m(xg2)
     monkeypatch.delenv("MSTG_ATTN_BLK4")
+    ops.refresh_env()
     grads2 = torch.autograd.grad(y2.abs().mean(), [xg2] + params)
     check_grads("G[c64_32x32] one-wave fwd, default bwd", ["dx"] + names, grads2, refs)
 
@@ -264,38 +267,131 @@ def _build_cyclegan(C, seeds):
 
 
 def test_train_step_vs_reference_golden(gold_dir):
-    """The reference's unmodified train_step (3 steps, C=8, 64x64, batch 2) against ours.  Step 0 is a pure function
-    of the inputs (1e-4; measured 3e-7).  Later steps inherit Adam's +-lr sign noise on elements whose gradient is
-    rounding noise, which the reference itself shows against its own restatement (oracle/make_golden.py: 2e-3).  Which
-    realisation of that noise a build lands on depends on summation order alone: tools/diag_step_drift.py measures
-    7e-4 at step 2 with the per-branch multi-scale kernels and 2.2e-3 with the fused ones, although both reproduce
-    torch's convolution to 3e-7 (tests/test_gpu_ops.py) and give bit-identical step-0 losses.  Hence 5e-3 here; the
-    backward path itself is held to 1e-3 by test_train_step_gradients_vs_oracle."""
+    """Step 0 of the reference's unmodified fp32 train_step (C=8, 64x64, batch 2) against ours: a pure function of the inputs
+    (1e-4; measured 3e-7).  Multi-step behaviour is pinned in fp64 by test_train_step_teacher_forced_vs_reference_fp64."""
     from oracle import restatement as R
     g = np.load(os.path.join(gold_dir, "train_step_c8_64x64.npz"))
     C, shape = int(g["C"]), tuple(g["shape"])
     model, sds = _build_cyclegan(C, [int(s) for s in g["seeds"]])
     keys = ("d_loss", "g_loss", "cycle_loss", "identity_loss", "structure_loss")
-    for step in range(3):
-        a, b = R.make_input(shape, 700 + 2 * step).to(DEV), R.make_input(shape, 701 + 2 * step).to(DEV)
+    a, b = R.make_input(shape, 700).to(DEV), R.make_input(shape, 701).to(DEV)
+    out = model.train_step(a, b)
+    ref = g["losses_0"]
+    print(f"  [parity] train_step 0: ours {[round(out[k], 6) for k in keys]}  reference {[round(float(r), 6) for r in ref]}")
+    for k, r in zip(keys, ref):
+        assert abs(out[k] - r) <= 1e-4 * max(1.0, abs(r)), (k, out[k], r)
+    for name, m, sd0 in (("G_AB", model.G_AB, sds[0]), ("D_A", model.D_A, sds[2])):
+        st = m.state_dict()
+        for k in st:
+            if k.startswith("style_encoder"):
+                assert torch.equal(st[k].cpu(), sd0[k]), k  # no gradient -> untouched, as with torch's Adam
+        assert rel_l2(torch.tensor(float(sum((st[k].cpu() - sd0[k]).double().pow(2).sum() for k in st)) ** 0.5),
+                      torch.tensor(float(g[f"delta_norm_0_{name}"]))) <= 2e-2
+
+
+def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
+    """Three steps of the train step against the reference's unmodified train_step run in fp64 (oracle/make_golden.py::
+    gen_train_step_fp64), TEACHER-FORCED: every step starts from the fp64 trajectory's state (parameters and Adam moments
+    re-derived in fp64 from the stored gradients, spectral-norm vectors from the fixture), so each step is held to its own
+    conditioning instead of to the chaos of Adam's lr*sign(g) updates.  Bar, per step / loss / live gradient tensor:
+        max(1e-3, 1.5 x the distance of the reference's own teacher-forced fp32 run from fp64)
+    (the fp32 evaluation of two chained generators flips ReLU masks; the reference's own fp32 gradients sit 3e-4 ... 4e-3 from
+    fp64 on this draw, the best of the scanned ones).  Also checked per step: Adam's first moment after the step against
+    b1*m + (1-b1)*g64 (relative), and the parameter update against the fp64 update on every element whose fp64 gradient is not
+    rounding noise."""
+    from fp64_fixture import BETAS, LOSS_KEYS, Fp64TrainStepFixture, dead_bias
+    from oracle import restatement as R
+    fx = Fp64TrainStepFixture(gold_dir)
+    model, sds = _build_cyclegan(fx.C, fx.seeds)
+    opts = {"g": model.g_optimizer, "d": model.d_optimizer}
+    mods = {"g": (model.G_AB, model.G_BA), "d": (model.D_A, model.D_B)}
+    for which in ("g", "d"):
+        assert [n for m in mods[which] for n, _ in m.named_parameters()] == fx.names[which]
+    p0 = {w: [p.detach().cpu().clone() for p in opts[w].params] for w in opts}
+    captured = {}
+    for which, opt in opts.items():
+        orig = opt.step
+
+        def step(_w=which, _opt=opt, _orig=orig):
+            captured[_w] = _opt.grad.clone()
+            _orig()
+        opt.step = step
+
+    def scatter(opt, flat, tensors):
+        with torch.no_grad():
+            for off, p, t in zip(opt.offsets, opt.params, tensors):
+                flat[off:off + p.numel()].copy_(t.reshape(-1).to(torch.float32))
+
+    worst = 0.0
+    for k in range(fx.steps):
+        expect = {}
+        for which, opt in opts.items():  # force the fp64 trajectory's state
+            p, m, v = fx.state_at(which, k, p0[which])
+            scatter(opt, opt.flat, p)
+            scatter(opt, opt.exp_avg, m)
+            scatter(opt, opt.exp_avg_sq, v)
+            opt.step_count = k
+            expect[which] = (p, m, v)
+        if k > 0:
+            for name, vec in fx.uv(k).items():
+                dn, key = name.split(".", 1)
+                getattr(model, dn).state_dict()[key].copy_(vec)
+        a = R.make_input(fx.shape, fx.in_seed + 2 * k).to(DEV)
+        b = R.make_input(fx.shape, fx.in_seed + 1 + 2 * k).to(DEV)
         out = model.train_step(a, b)
-        ref = g[f"losses_{step}"]
-        tol = 1e-4 if step == 0 else 5e-3
-        print(f"  [parity] train_step {step}: ours {[round(out[k], 6) for k in keys]}  reference {[round(float(r), 6) for r in ref]}")
-        for k, r in zip(keys, ref):
-            assert abs(out[k] - r) <= tol * max(1.0, abs(r)), (step, k, out[k], r)
-        if step == 0:
-            for name, m, sd0, lr in (("G_AB", model.G_AB, sds[0], 5e-5), ("D_A", model.D_A, sds[2], 2e-4)):
-                st = m.state_dict()
-                for k in st:
-                    if k.startswith("style_encoder"):
-                        assert torch.equal(st[k].cpu(), sd0[k]), k  # no gradient -> untouched, as with torch's Adam
-                assert rel_l2(torch.tensor(float(sum((st[k].cpu() - sd0[k]).double().pow(2).sum() for k in st)) ** 0.5),
-                              torch.tensor(float(g[f"delta_norm_0_{name}"]))) <= 2e-2
-    w = model.G_AB.state_dict()["output.0.weight"].cpu()
-    assert float((w - _t(g["final_G_AB_output.0.weight"])).abs().max()) <= 2.1 * 5e-5 * 3
-    u = model.D_A.state_dict()["main.0.weight_u"].cpu()
-    assert rel_l2(u, _t(g["final_D_A_main.0.weight_u"])) <= 1e-2
+        ref, ref32 = fx.losses64(k), fx.losses32(k)
+        for key in LOSS_KEYS:
+            bound = max(1e-3, 1.5 * abs(ref32[key] - ref[key]) / max(1.0, abs(ref[key])))
+            err = abs(out[key] - ref[key]) / max(1.0, abs(ref[key]))
+            assert err <= bound, (k, key, out[key], ref[key], bound)
+        for which, opt in opts.items():
+            ours = captured[which].cpu().double()
+            dist32, agg32 = fx.ref32_dist(which, k)
+            num = den = 0.0
+            p_before, m_before, _ = expect[which]
+            m_flat = opt.exp_avg.detach().cpu().double()
+            m_num = m_den = 0.0
+            for i, (n, off, prm, r) in enumerate(zip(fx.names[which], opt.offsets, opt.params, fx.grads(which, k))):
+                mine = ours[off:off + prm.numel()]
+                if r is None:
+                    assert float(mine.abs().max()) == 0.0, (k, n)
+                    continue
+                r = r.reshape(-1)
+                if dead_bias(n):
+                    continue
+                e = float((mine - r).norm() / r.norm().clamp_min(1e-300))
+                bound = max(1e-3, 1.5 * dist32[i])
+                worst = max(worst, e / bound)
+                assert e <= bound, (k, which, n, e, bound, dist32[i])
+                num += float((mine - r).pow(2).sum())
+                den += float(r.pow(2).sum())
+                # Adam's first moment after the step: linear in the gradient
+                m_exp = BETAS[0] * m_before[i].reshape(-1) + (1 - BETAS[0]) * r
+                m_num += float((m_flat[off:off + prm.numel()] - m_exp).pow(2).sum())
+                m_den += float(m_exp.pow(2).sum())
+                # parameter update (checked below) on elements whose gradient is not rounding noise (|g| > 1e-2 rms)
+                live = r.abs() > 1e-2 * float(r.pow(2).mean().sqrt())
+                expect.setdefault(("live", which), []).append((i, off, prm.numel(), live))
+            agg = (num / max(den, 1e-300)) ** 0.5
+            print(f"  [parity] fp64-forced step {k} {which}-gradients: aggregate {agg:.2e} (reference's own fp32: {agg32:.2e})")
+            assert agg <= max(1e-3, 1.5 * agg32), (k, which, agg, agg32)
+            assert (m_num / max(m_den, 1e-300)) ** 0.5 <= max(1e-3, 1.5 * agg32), (k, which, "exp_avg")
+        # update direction / size: the state after this step vs the fp64 state at the start of the next one
+        for which, opt in opts.items():
+            p_next, _, _ = fx.state_at(which, k + 1, p0[which])
+            after_flat = opt.flat.detach().cpu().double()
+            p_before = expect[which][0]
+            dn = dd = 0.0
+            for i, off, n_el, live in expect[("live", which)]:
+                d_ours = (after_flat[off:off + n_el] - p_before[i].reshape(-1))[live]
+                d_ref = (p_next[i].reshape(-1) - p_before[i].reshape(-1))[live]
+                dn += float((d_ours - d_ref).pow(2).sum())
+                dd += float(d_ref.pow(2).sum())
+            rel_upd = (dn / max(dd, 1e-300)) ** 0.5
+            print(f"  [parity] fp64-forced step {k} {which}-update on live elements: rel-L2 {rel_upd:.2e}")
+            assert rel_upd <= 5e-2, (k, which, rel_upd)
+            expect.pop(("live", which))
+    print(f"  [parity] fp64-forced: worst tensor at {worst:.2f} of its bound")
 
 
 def test_train_step_gradients_vs_oracle():
@@ -419,6 +515,44 @@ def test_module_level_switches_keep_parity(env, gold_dir, monkeypatch):
     kernel families) against the same golden vectors as the defaults."""
     k, v = env.split("=")
     monkeypatch.setenv(k, v)
+    from mstg_hip import ops
+    ops.refresh_env()
     test_generator_vs_reference_golden(gold_dir, "c16_64x64", False)
     test_discriminator_vs_reference_golden(gold_dir)
     test_train_step_vs_reference_golden(gold_dir)
+
+
+def test_save_models_round_trip(tmp_path):
+    """save_models writes the reference's three checkpoint files (enhanced_train.py:133-152) holding ONLY each model's own
+    tensors (parameters are views of the optimizers' flat buffers: the files must not carry the whole buffer), a fresh model
+    strict-loads them, and the files load the way the reference's inference scripts do (advanced_transform.py:14-32)."""
+    import enhanced_generator as eg
+    import enhanced_train
+    model, _ = _build_cyclegan(8, [11, 12, 13, 14])
+    g = torch.Generator().manual_seed(3)
+    a = (torch.rand((1, 3, 32, 32), generator=g) * 2 - 1).to(DEV)
+    b = (torch.rand((1, 3, 32, 32), generator=g) * 2 - 1).to(DEV)
+    model.train_step(a, b)
+    model.save_models(tmp_path, 20)
+    n_g = sum(v.numel() for v in model.G_AB.state_dict().values())
+    size = (tmp_path / "G_AB_epoch_20.pth").stat().st_size
+    assert size < 4 * n_g + 65536, f"G_AB checkpoint is {size} bytes for {n_g} floats: it carries more than its own tensors"
+    fresh = enhanced_train.EnhancedCycleGAN(channels=8, num_transformer_blocks=0, device=torch.device(DEV))
+    assert fresh.load_models(tmp_path, 20) == 20
+    for m_old, m_new in ((model.G_AB, fresh.G_AB), (model.G_BA, fresh.G_BA), (model.D_A, fresh.D_A), (model.D_B, fresh.D_B)):
+        for (k, v), (k2, v2) in zip(m_old.state_dict().items(), m_new.state_dict().items()):
+            assert k == k2 and torch.equal(v, v2), k
+    fresh.g_optimizer.check_views()
+    fresh.d_optimizer.check_views()
+    la, lb = model.train_step(a, b), fresh.train_step(a, b)  # Adam moments are not part of the reference's checkpoints
+    assert la["cycle_loss"] == lb["cycle_loss"] and la["identity_loss"] == lb["identity_loss"]
+    ckpt = torch.load(tmp_path / "G_AB_epoch_20.pth", map_location="cpu", weights_only=True)
+    assert set(ckpt) == {"epoch", "G_AB_state_dict"} and ckpt["epoch"] == 20
+    g2 = eg.EnhancedGenerator(channels=8, num_transformer_blocks=0)
+    g2.load_state_dict(ckpt["G_AB_state_dict"])
+    d = torch.load(tmp_path / "discriminators_epoch_20.pth", map_location="cpu", weights_only=True)
+    assert set(d) == {"epoch", "D_A_state_dict", "D_B_state_dict"}
+    # moving a module after its optimizer was built is caught, not silently ignored
+    model.G_AB.half()
+    with pytest.raises(RuntimeError, match="flat buffer"):
+        model.g_optimizer.step()

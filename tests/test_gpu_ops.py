@@ -128,6 +128,8 @@ def test_conv_stream_kernel(case, monkeypatch):
     checks as the default kernels: interior fast path, border tiles, dpack exchange, channel chunks, parity classes."""
     from mstg_hip import _lib
     monkeypatch.setenv("MSTG_STREAM", "1f")
+    from mstg_hip import ops as _ops
+    _ops.refresh_env()
     name, N, H, W, Cin, Cout, k, s, p, d, tr, x_nchw, y_nchw, act = case
     Ho, Wo = (2 * H, 2 * W) if tr else ((H + 2 * p - d * (k - 1) - 1) // s + 1, (W + 2 * p - d * (k - 1) - 1) // s + 1)
     from mstg_hip import ops
@@ -206,6 +208,8 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
     monkeypatch.setenv(k, v)
+    from mstg_hip import ops as _ops
+    _ops.refresh_env()
     test_conv_channel_slices_and_accumulate(2, 21, 37, 16)
     test_conv_channel_slices_and_accumulate(1, 32, 32, 32)
     for case in CONV_CASES:

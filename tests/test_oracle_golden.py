@@ -150,3 +150,40 @@ def test_train_step(gold_dir):
             assert abs(out[k] - r) <= tol * max(1.0, abs(r)), (step, k, out[k], r)
     w = model.G_AB["output.0.weight"].detach()
     assert float((w - _t(g["final_G_AB_output.0.weight"])).abs().max()) <= 2.1 * 5e-5 * 3
+
+
+def test_train_step_fp64_pin(gold_dir):
+    """The restated train step run in fp64, free-running for three steps, against the reference's unmodified train_step run in
+    fp64 (tests/golden/train_step_fp64_c8.npz): losses to 1e-9, every gradient both optimizers see to 1e-6 (the fixture stores
+    the fp64 gradients rounded to fp32), and the Adam state derived by tests/fp64_fixture.py equals the oracle's own."""
+    from fp64_fixture import Fp64TrainStepFixture, LOSS_KEYS, dead_bias
+    fx = Fp64TrainStepFixture(gold_dir)
+    C, shape, seeds = fx.C, fx.shape, fx.seeds
+    sds = [R.make_state_dict(R.generator_spec(C), seeds[0]), R.make_state_dict(R.generator_spec(C), seeds[1]),
+           R.make_state_dict(R.discriminator_spec(C), seeds[2]), R.make_state_dict(R.discriminator_spec(C), seeds[3])]
+    model = R.CycleGANOracle(*[{k: v.double() for k, v in sd.items()} for sd in sds])
+    assert [k for _, k in model.g_keys] == fx.names["g"] and [k for _, k in model.d_keys] == fx.names["d"]
+    got = {}
+    for which, opt in (("d", model.d_opt), ("g", model.g_opt)):
+        orig = opt.step
+
+        def step(grads, _w=which, _orig=orig):
+            got[_w] = grads
+            _orig(grads)
+        opt.step = step
+    p0 = {"g": [sd[k].detach().clone() for sd, k in model.g_keys], "d": [sd[k].detach().clone() for sd, k in model.d_keys]}
+    for k in range(fx.steps):
+        a, b = R.make_input(shape, fx.in_seed + 2 * k).double(), R.make_input(shape, fx.in_seed + 1 + 2 * k).double()
+        for which, keys in (("g", model.g_keys), ("d", model.d_keys)):  # state derived from the stored gradients == oracle's state
+            p, _, _ = fx.state_at(which, k, p0[which])
+            for (sd, key), pe in zip(keys, p):
+                assert float((sd[key].detach() - pe).abs().max()) <= 1e-9, (k, which, key)
+        out = model.train_step(a, b)
+        ref = fx.losses64(k)
+        for key in LOSS_KEYS:
+            assert abs(out[key] - ref[key]) <= 1e-9 * max(1.0, abs(ref[key])), (k, key, out[key], ref[key])
+        for which in ("g", "d"):
+            for n, mine, r in zip(fx.names[which], got[which], fx.grads(which, k)):
+                assert (mine is None) == (r is None), (which, n)
+                if r is not None and not dead_bias(n):
+                    assert rel_l2(mine, r.view_as(mine)) <= 1e-6, (k, which, n)
