@@ -193,6 +193,44 @@ int mstg_gram_fwd(const float* f, float* g, int N, int HW, int C, float scale, v
                   void* stream);
 int mstg_gram_bwd(const float* f, const float* dg, float* df, int N, int HW, int C, float scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Inference-only forward in fp16 storage / fp16 MFMA / fp32 accumulation (BASELINE config #5).  Replaces
+ * EnhancedGenerator.forward as the reference's inference scripts call it under torch.no_grad()
+ * (direct_transform.py:62-63, batch_process_images.py:210-211, advanced_transform.py:99-100).
+ * Activations between calls are NHWC fp16; statistics, softmax and every accumulation are fp32.
+ * InstanceNorm is split: a convolution that feeds a norm also returns that norm's (mean, rstd) per
+ * (image, channel) in `out_stats` [N][Cout][2]; the consumer of the normalised tensor takes them as
+ * `in_stats` and applies (x - mean) * rstd -> ReLU while staging its input (nn.InstanceNorm2d + nn.ReLU
+ * at enhanced_generator.py:54-75,93-94,100-101,107-108,122-123,129-130 never touch HBM on this path).
+ * Filters are packed ONCE per weight set (inference: weights are frozen) into an opaque device blob.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mstg_f16_conv_desc {
+    int32_t kind;         /* 0: nn.Conv2d; 1: nn.ConvTranspose2d(k4,s2,p1); 2: the four MultiScaleBlock branch convs (:52-71) as one */
+    int32_t N, H, W, Cin; /* source (N,H,W,Cin) NHWC fp16 with Cin in {16,32,64}, or (N,Cin,H,W) NCHW fp32 with Cin <= 4 */
+    int32_t Ho, Wo, Cout; /* destination (N,Ho,Wo,Cout) NHWC fp16 (Cout <= 64, multiple of 4) or (N,Cout,Ho,Wo) NCHW fp16 (Cout <= 4) */
+    int32_t K, stride, pad, dil;
+    int32_t src_nchw_f32; /* 1: the 3-channel fp32 image at the module boundary (stem) */
+    int32_t dst_nchw;     /* 1: the 3-channel output image (head) */
+    int32_t act;          /* MSTG_ACT_NONE or MSTG_ACT_TANH (dst_nchw only) */
+} mstg_f16_conv_desc;
+size_t mstg_f16_conv_plan_bytes(const mstg_f16_conv_desc* d); /* size of the packed-filter blob; 0 = unsupported geometry */
+/* w0/b0: the layer's fp32 weight (OIHW, or IOHW for kind 1) and bias (nullable); kind 2: w0..w3 / b0..b3 = branch1..branch4 */
+int mstg_f16_conv_pack(const mstg_f16_conv_desc* d, const float* w0, const float* b0, const float* w1, const float* b1,
+                       const float* w2, const float* b2, const float* w3, const float* b3, void* blob, size_t blob_bytes,
+                       void* stream);
+size_t mstg_f16_conv_partial_bytes(const mstg_f16_conv_desc* d); /* workspace needed when out_stats != NULL */
+int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats /*nullable*/, void* y,
+                      float* out_stats /*nullable*/, void* workspace, size_t workspace_bytes, void* stream);
+/* y = relu((x - mean) * rstd) + residual (nullable): the fusion conv's norm and the block's `+ x` (:84); NHWC fp16 */
+int mstg_f16_norm_residual(const void* x, const void* residual, const float* stats, void* y, int N, int HW, int C, void* stream);
+/* whole LocalAttention module (:13-47) on NHWC fp16, C in {16,32,64}; in_stats (nullable) = normalise + ReLU on load of x;
+ * params = blob from mstg_f16_attn_pack (qkv and proj 1x1 filters as fp16 MFMA fragments + fp32 biases) */
+size_t mstg_f16_attn_plan_bytes(int C);
+int mstg_f16_attn_pack(const float* wqkv, const float* bqkv, const float* wproj, const float* bproj, int C, void* blob,
+                       size_t blob_bytes, void* stream);
+int mstg_f16_attn_fwd(const void* x, const float* in_stats /*nullable*/, const void* blob, void* y, int N, int H, int W, int C,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,24 @@ class EnhancedGenerator(nn.Module):
             m.requires_grad_(True)
         self.use_checkpointing = True
 
+    def half_inference(self, enable: bool = True):
+        """Inference-only fast path (BASELINE config #5): fp16 storage, fp16 MFMA, fp32 accumulation / statistics / softmax.
+        Under ``torch.no_grad()`` ``forward`` then runs csrc/infer_f16.hip (mstg_hip/infer.py) and returns an fp16 (N,3,H,W)
+        tensor; with autograd enabled the fp32 training path still runs.  The packed fp16 filters are rebuilt lazily after a
+        ``load_state_dict``; call ``half_inference()`` again after changing weights in any other way."""
+        self._half_enabled = bool(enable)
+        self._half_plan = None
+        if enable and not getattr(self, "_half_hook", False):
+            self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_half_plan", None))
+            self._half_hook = True
+        return self
+
+    def _half(self):
+        if getattr(self, "_half_plan", None) is None:
+            from mstg_hip.infer import HalfGeneratorPlan
+            self._half_plan = HalfGeneratorPlan(self)
+        return self._half_plan
+
     def _run(self, fn, *args):
         if getattr(self, "use_checkpointing", False) and torch.is_grad_enabled():
             return torch.utils.checkpoint.checkpoint(fn, *args, use_reentrant=False)
@@ -149,6 +167,8 @@ class EnhancedGenerator(nn.Module):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise RuntimeError(f"EnhancedGenerator: H and W must be multiples of 16 (two stride-2 stages and 4x4 windows), "
                                f"got {x.shape[2]}x{x.shape[3]}")
+        if getattr(self, "_half_enabled", False) and not torch.is_grad_enabled():
+            return self._half().forward(x, taps)
         orig_input = x
         h = self.initial[0](x, nhwc=True, x_nchw=True)          # NCHW image -> NHWC features inside the stem conv
         h = ops.instnorm_act(h, ACT_RELU)

@@ -18,8 +18,15 @@ class ConvDesc(C.Structure):
         "x_nchw", "y_nchw", "x_ctot", "x_coff", "y_ctot", "y_coff", "act", "accumulate")]
 
 
+class F16ConvDesc(C.Structure):
+    """mirror of mstg_f16_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "kind", "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "K", "stride", "pad", "dil", "src_nchw_f32", "dst_nchw", "act")]
+
+
 _vp, _fp, _sz, _i, _f = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float
 _dp = C.POINTER(ConvDesc)
+_hp = C.POINTER(F16ConvDesc)
 
 # name -> (restype, argtypes); the test-suite checks that every symbol declared in include/mstg_hip.h is here
 SIGNATURES = {
@@ -69,6 +76,14 @@ SIGNATURES = {
     "mstg_spectral_norm_workspace_bytes": (_sz, [_i, _i]),
     "mstg_spectral_norm_fwd": (_i, [_fp] * 7 + [_i, _i, _f, _i, _vp, _sz, _vp]),
     "mstg_spectral_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_f16_conv_plan_bytes": (_sz, [_hp]),
+    "mstg_f16_conv_pack": (_i, [_hp] + [_fp] * 8 + [_vp, _sz, _vp]),
+    "mstg_f16_conv_partial_bytes": (_sz, [_hp]),
+    "mstg_f16_conv_fwd": (_i, [_hp, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),
+    "mstg_f16_norm_residual": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _vp]),
+    "mstg_f16_attn_plan_bytes": (_sz, [_i]),
+    "mstg_f16_attn_pack": (_i, [_fp, _fp, _fp, _fp, _i, _vp, _sz, _vp]),
+    "mstg_f16_attn_fwd": (_i, [_vp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None
