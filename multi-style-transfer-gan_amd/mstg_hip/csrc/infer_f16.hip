@@ -16,6 +16,7 @@
 // padded to 4, two horizontally adjacent taps x 4 channels): one 16-byte LDS read per lane.  The LDS pixel stride is
 // 2*Cin + 16 bytes, which makes those reads bank-conflict free for Cin = 16 / 32 / 64 (MI355X_MICROARCH.md, LDS).
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -27,17 +28,26 @@ namespace mstg {
 
 constexpr int F16_MAX_STEPS = 64;
 constexpr int F16_TW = 16;  // tile width in output pixels of the compute grid (= one MFMA N fragment)
+constexpr int F16_MAX_GRID = 1024;  // persistent workgroups: 256 CUs x at most 4
+constexpr int F16_TABLE_BYTES = (64 + 4) * 16;  // K-step table + class table at the start of the kernel's LDS
 
 // how the pack kernel fills one half (4 k-elements) of a lane group
 enum : int8_t { PK_ZERO = 0, PK_CONV = 1, PK_CONVT = 2, PK_MS_CENTER = 3, PK_MS_RING1 = 4 /* +0,1,2 = branches 2,3,4 */ };
 struct PackHalf { int8_t mode, ky, kx; int8_t pad; int16_t cb; };
-struct PackTable { PackHalf h[F16_MAX_STEPS][4][2]; };
+struct PackTable {
+    PackHalf h[F16_MAX_STEPS][4][2];
+    uint8_t pair_step[F16_MAX_STEPS * 4], pair_frag[F16_MAX_STEPS * 4];  // stored fragment -> (K-step, output fragment)
+};
 
 struct F16Plan {
     int nsteps, ncls;
     int cls_begin[5];
     uint16_t koff[F16_MAX_STEPS][4];  // byte offset of the group's 16 bytes relative to the lane's pixel base in the patch
     uint8_t fmask[F16_MAX_STEPS];     // output-channel fragments the step feeds
+    uint16_t wofs[F16_MAX_STEPS];     // index of the step's first stored filter fragment (only the fragments in fmask are stored)
+    int nwfrag, wlds;                 // stored fragments in all; 1: the kernel keeps the filter in LDS
+    unsigned m_pw;                    // magic multiplier for division by PW
+    int npf;                          // 16-byte patch elements per thread
     int8_t cls_oy[4], cls_ox[4];      // ConvTranspose: output parity of the class
     int PH, PW, pixstride;            // patch rows / cols / bytes per pixel
     int oy0, ox0;                     // patch origin = tile origin * stride + (oy0, ox0)
@@ -56,6 +66,7 @@ struct F16ConvArgs {
     int Gh, Gw;             // compute grid per image (= Ho x Wo, or H x W for up)
     int tiles_x, tiles_y;
     int act;
+    int dbg;  // experiments (MSTG_F16_DBG): 1 skip K-steps, 2 skip stores, 4 skip patch fetch, 8 skip commit
 };
 
 template <int CTRL>
@@ -79,10 +90,10 @@ struct PackSrc {
     int Cin, Cout, KH, KW, c4;  // c4: channels per MultiScaleBlock branch
 };
 
-__global__ void f16_pack_kernel(PackTable t, PackSrc s, int nsteps, int NF, h16* __restrict__ wpk, float* __restrict__ bias) {
-    const int total = nsteps * NF * 64 * 8;
+__global__ void f16_pack_kernel(PackTable t, PackSrc s, int nwfrag, int NF, h16* __restrict__ wpk, float* __restrict__ bias) {
+    const int total = nwfrag * 64 * 8;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int j = e & 7, lane = (e >> 3) & 63, f = (e >> 9) % NF, step = (e >> 9) / NF;
+        const int j = e & 7, lane = (e >> 3) & 63, f = t.pair_frag[e >> 9], step = t.pair_step[e >> 9];
         const int m = lane & 15, g = lane >> 4, hf = j >> 2, jj = j & 3;
         const PackHalf ph = t.h[step][g][hf];
         const int co = 16 * f + m, ci = ph.cb + jj;
@@ -114,159 +125,190 @@ __global__ void f16_pack_kernel(PackTable t, PackSrc s, int nsteps, int NF, h16*
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
-// the convolution kernel.  256 threads; wave w computes rows RPW*w .. RPW*w + RPW-1 of a (4*RPW) x 16 tile of the compute grid
-// for all 16*NF output channels.
+// the convolution kernel.  Persistent workgroups of 256 threads; wave w computes rows RPW*w .. RPW*w + RPW-1 of a (4*RPW) x 16
+// tile of the compute grid for all 16*NF output channels.  Per workgroup: the packed filter is copied into LDS once (when it
+// fits next to the patch: p.wlds), then for every tile
+//     registers (prefetched patch) -> [InstanceNorm + ReLU] -> LDS | barrier | issue the NEXT tile's patch loads |
+//     K-steps (operands of step s+1 are read while the MFMAs of step s run) | epilogue: bias, statistics, store | barrier
+// so the global round trip of a patch hides behind the previous tile's arithmetic.
 // -------------------------------------------------------------------------------------------------------------------------
-template <int RPW, int NF, int SRC, int DST>
+struct TrueT { static constexpr bool value = true; };
+struct FalseT { static constexpr bool value = false; };
+
+template <int NPF, int SRC>
+struct PatchRegs {
+    h16x8 v[SRC == 0 ? NPF : 1];
+    f32x4 f[SRC == 1 ? NPF : 1];
+    unsigned okmask;
+};
+
+// What a thread stages is the same for every tile: element k of thread tid is patch pixel (r, c) [and channel octet o], i.e. a
+// fixed byte offset from the patch origin in the source and a fixed LDS address.  Computed once per kernel; an interior tile
+// (the whole patch inside the image: almost all of them) then costs one load and one LDS write per element and no arithmetic.
+template <int NPF>
+struct PatchGeom {
+    unsigned rel[NPF];   // byte offset in the source image relative to the patch origin (SRC 1: within one plane)
+    unsigned dst[NPF];   // LDS byte offset
+    unsigned rc[NPF];    // r << 16 | c
+    unsigned vmask;      // element exists
+};
+
+template <int NPF, int SRC>
+__device__ __forceinline__ void patch_geom(const F16ConvArgs& a, const F16Plan& p, int tid, PatchGeom<NPF>& Gm) {
+    Gm.vmask = 0;
+    const int oct = SRC == 0 ? (a.Cin >> 3) : 1, o = tid & (oct - 1), sh = oct == 1 ? 0 : (oct == 2 ? 1 : (oct == 4 ? 2 : 3));
+    const int total = p.PH * p.PW * oct;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int e = 256 * k + tid;
+        const int pix = e >> sh;
+        const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
+        if (e < total) Gm.vmask |= 1u << k;
+        Gm.rc[k] = ((unsigned)r << 16) | (unsigned)c;
+        if (SRC == 0) {
+            Gm.rel[k] = (unsigned)(((r * a.W + c) * a.Cin + 8 * o) * 2);
+            Gm.dst[k] = (unsigned)(pix * p.pixstride + 16 * o);
+        } else {
+            Gm.rel[k] = (unsigned)((r * a.W + c) * 4);
+            Gm.dst[k] = (unsigned)(pix * 8);
+        }
+    }
+}
+
+// tile index -> (image, tile row, tile column); consecutive tiles stay on one XCD (blocks b and b + 8 share an XCD)
+__device__ __forceinline__ int persistent_tile(int it, int b, int G) { return it * G + (b & 7) * (G >> 3) + (b >> 3); }
+
+template <int NPF, int SRC>
+__device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan& p, int t, int TH, const PatchGeom<NPF>& Gm,
+                                            PatchRegs<NPF, SRC>& R) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int n = t / ntile, tt = t - n * ntile;
+    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * F16_TW * p.stride + p.ox0;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + p.PH <= a.H && sx0 + p.PW <= a.W;  // uniform
+    if (SRC == 0) {
+        const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 2;
+        if (interior) {
+            const char* org = img + ((size_t)sy0 * a.W + sx0) * a.Cin * 2;
+            R.okmask = Gm.vmask;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) R.v[k] = *reinterpret_cast<const h16x8*>(org + (((Gm.vmask >> k) & 1) ? Gm.rel[k] : 0u));
+        } else {
+            R.okmask = 0;
+            const long org = ((long)sy0 * a.W + sx0) * a.Cin * 2;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int iy = sy0 + (int)(Gm.rc[k] >> 16), ix = sx0 + (int)(Gm.rc[k] & 0xffffu);
+                const bool ok = ((Gm.vmask >> k) & 1) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                R.okmask |= (unsigned)ok << k;
+                R.v[k] = *reinterpret_cast<const h16x8*>(img + (ok ? org + (long)Gm.rel[k] : 0L));
+            }
+        }
+    } else {
+        const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.Cin * a.H * a.W * 4;
+        const size_t plane = (size_t)a.H * a.W * 4;
+        R.okmask = 0;
+        const long org = ((long)sy0 * a.W + sx0) * 4;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int iy = sy0 + (int)(Gm.rc[k] >> 16), ix = sx0 + (int)(Gm.rc[k] & 0xffffu);
+            const bool ok = ((Gm.vmask >> k) & 1) && (interior || ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W));
+            R.okmask |= (unsigned)ok << k;
+            const char* q = img + (ok ? org + (long)Gm.rel[k] : 0L);
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            w[0] = *reinterpret_cast<const float*>(q);
+            if (a.Cin > 1) w[1] = *reinterpret_cast<const float*>(q + plane);
+            if (a.Cin > 2) w[2] = *reinterpret_cast<const float*>(q + 2 * plane);
+            if (a.Cin > 3) w[3] = *reinterpret_cast<const float*>(q + 3 * plane);
+            R.f[k] = w;
+        }
+    }
+}
+
+template <int NPF, int SRC>
+__device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan& p, int n, int tid, const PatchGeom<NPF>& Gm,
+                                             const PatchRegs<NPF, SRC>& R, unsigned char* patch) {
+    if (SRC == 0) {
+        const int oct = a.Cin >> 3, o = tid & (oct - 1);
+        const bool norm = a.in_stats != nullptr;
+        float sc[8], nb[8];  // (x - mean) * rstd = x * sc + nb
+        if (norm) {
+            const float* st = a.in_stats + ((size_t)n * a.Cin + 8 * o) * 2;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sc[c] = st[2 * c + 1]; nb[c] = -st[2 * c] * st[2 * c + 1]; }
+        }
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            if ((Gm.vmask >> k) & 1) {
+                h16x8 w = R.v[k];
+                if (norm) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[c] = (h16)fmaxf(fmaf((float)w[c], sc[c], nb[c]), 0.f);
+                }
+                if (!((R.okmask >> k) & 1)) w = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // zero padding applies to the NORMALISED activation
+                *reinterpret_cast<h16x8*>(patch + Gm.dst[k]) = w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            if ((Gm.vmask >> k) & 1) {
+                h16x4 w;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) w[ch] = ((R.okmask >> k) & 1) ? (h16)R.f[k][ch] : (h16)0;
+                *reinterpret_cast<h16x4*>(patch + Gm.dst[k]) = w;
+            }
+        }
+    }
+}
+
+template <int RPW, int NF, int SRC, int DST, int NPF, bool WLDS>
 __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 4 * RPW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int ntile = a.tiles_x * a.tiles_y;
-    int t = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int n = t / ntile;
-    t -= n * ntile;
-    const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
-    const int gy0 = ty * TH, gx0 = tx * F16_TW;                       // tile origin in the compute grid
-    const int sy0 = gy0 * p.stride + p.oy0, sx0 = gx0 * p.stride + p.ox0;  // patch origin in the source
-
-    // ---- stage the patch --------------------------------------------------------------------------------------------------
-    if (SRC == 0) {
-        const h16* src = reinterpret_cast<const h16*>(a.x) + (size_t)n * a.H * a.W * a.Cin;
-        const int oct = a.Cin >> 3;                    // 16-byte chunks per pixel (a power of two: 2, 4, 8)
-        const int total = p.PH * p.PW * oct;
-        const int o = tid & (oct - 1);                  // this thread's channel octet: the same for all its elements
-        float mu[8], rs[8];
-        const bool norm = a.in_stats != nullptr;
-        if (norm) {
-            const float* st = a.in_stats + ((size_t)n * a.Cin + 8 * o) * 2;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) { mu[c] = st[2 * c]; rs[c] = st[2 * c + 1]; }
-        }
-        for (int e0 = 0; e0 < total; e0 += 1024) {
-            h16x8 v[4];
-            bool ok[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + 256 * k + tid;
-                const int pix = e / oct;
-                const int r = pix / p.PW, c = pix - r * p.PW;
-                const int iy = sy0 + r, ix = sx0 + c;
-                ok[k] = e < total && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-                const size_t off = ok[k] ? ((size_t)iy * a.W + ix) * a.Cin + 8 * o : 0;
-                v[k] = *reinterpret_cast<const h16x8*>(src + off);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = e0 + 256 * k + tid;
-                if (e < total) {
-                    h16x8 w = v[k];
-                    if (norm) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float f = ((float)w[c] - mu[c]) * rs[c];
-                            w[c] = (h16)(f > 0.f ? f : 0.f);
-                        }
-                    }
-                    if (!ok[k]) w = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // zero padding applies to the NORMALISED activation
-                    *reinterpret_cast<h16x8*>(smem + (size_t)(e / oct) * p.pixstride + 16 * o) = w;
-                }
-            }
-        }
-    } else {  // NCHW fp32 image with Cin (<= 4) planes -> [pixel][4] fp16
-        const float* src = reinterpret_cast<const float*>(a.x) + (size_t)n * a.Cin * a.H * a.W;
-        const int total = p.PH * p.PW;
-        const size_t plane = (size_t)a.H * a.W;
-        for (int e = tid; e < total; e += 256) {
-            const int r = e / p.PW, c = e - r * p.PW;
-            const int iy = sy0 + r, ix = sx0 + c;
-            h16x4 w = {0, 0, 0, 0};
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-                const size_t off = (size_t)iy * a.W + ix;
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
-                    if (ch < a.Cin) w[ch] = (h16)src[ch * plane + off];
-            }
-            *reinterpret_cast<h16x4*>(smem + (size_t)e * 8) = w;
-        }
-    }
-    __syncthreads();
-
-    // ---- main loop ----------------------------------------------------------------------------------------------------------
     const int nl = lane & 15, g = lane >> 4;
+    const int ntile = a.tiles_x * a.tiles_y, total_tiles = a.N * ntile, G = gridDim.x;
+    const bool want_stats = a.partial != nullptr;
+    // LDS: [K-step table: 64 x 16 B | class table: 4 x 16 B] [filter (p.wlds)] [patch] ; the statistics scratch aliases the patch.
+    // The tables live in LDS, not in the kernel-argument segment: a dynamically indexed kernarg read is a scalar load whose wait
+    // (lgkmcnt(0): scalar loads return out of order) also drains every LDS read in flight -- measured 700-3000 cycles per K-step.
+    unsigned char* wl = smem + F16_TABLE_BYTES;
+    unsigned char* patch = wl + (WLDS ? (size_t)p.nwfrag * 1024 : 0);
+    if (tid < F16_MAX_STEPS) {
+        uint16_t* e = reinterpret_cast<uint16_t*>(smem + 16 * tid);
+        e[0] = p.koff[tid][0]; e[1] = p.koff[tid][1]; e[2] = p.koff[tid][2]; e[3] = p.koff[tid][3];
+        e[4] = p.fmask[tid]; e[5] = p.wofs[tid];
+    } else if (tid < F16_MAX_STEPS + 4) {
+        const int c = tid - F16_MAX_STEPS;
+        int* e = reinterpret_cast<int*>(smem + 16 * tid);
+        e[0] = p.cls_begin[c]; e[1] = p.cls_begin[c + 1]; e[2] = p.cls_oy[c]; e[3] = p.cls_ox[c];
+    }
+    if (WLDS) {
+        const int nchunk = p.nwfrag * 64;
+        for (int e = tid; e < nchunk; e += 256) reinterpret_cast<h16x8*>(wl)[e] = reinterpret_cast<const h16x8*>(a.wpk)[e];
+    }
+    // the address space must be static: a pointer that is "LDS or global" compiles to flat loads, whose waits drain both counters
+    const h16x8* wglob = reinterpret_cast<const h16x8*>(a.wpk) + lane;
+    const unsigned char* wlds_lane = wl + 16 * lane;
+    const int ncls = p.ncls, up = p.up, pixstride = p.pixstride;
     unsigned base[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) base[r] = (unsigned)(((RPW * wv + r) * p.stride * p.PW + nl * p.stride) * p.pixstride);
+    (void)pixstride;
+    f32x4 b4[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b4[f] = *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
+
+    // statistics of what this workgroup writes, per channel: kept in registers across the tiles of one image and flushed to
+    // partial[image][workgroup] when the image changes (the buffer is zeroed by the host: not every workgroup sees every image)
     float ssum[NF][4], ssq[NF][4];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ssum[f][r] = ssq[f][r] = 0.f;
-    const bool want_stats = a.partial != nullptr;
-    const h16x8* wp = reinterpret_cast<const h16x8*>(a.wpk) + lane;
-
-    for (int cls = 0; cls < p.ncls; ++cls) {
-        f32x4 acc[RPW][NF];
-#pragma unroll
-        for (int r = 0; r < RPW; ++r)
-#pragma unroll
-            for (int f = 0; f < NF; ++f) acc[r][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int s0 = p.cls_begin[cls], s1 = p.cls_begin[cls + 1];
-        for (int s = s0; s < s1; ++s) {
-            const unsigned k0 = p.koff[s][0], k1 = p.koff[s][1], k2 = p.koff[s][2], k3 = p.koff[s][3];
-            const unsigned ko = g == 0 ? k0 : (g == 1 ? k1 : (g == 2 ? k2 : k3));
-            const unsigned fm = p.fmask[s];
-            h16x8 bf[RPW];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) bf[r] = *reinterpret_cast<const h16x8*>(smem + base[r] + ko);
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                if (NF == 1 || ((fm >> f) & 1)) {
-                    const h16x8 af = wp[(size_t)(s * NF + f) * 64];
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r) acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[r], acc[r][f], 0, 0, 0);
-                }
-            }
-        }
-        // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) -----------
-        const int oyc = p.up ? p.cls_oy[cls] : 0, oxc = p.up ? p.cls_ox[cls] : 0, mul = p.up ? 2 : 1;
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int gy = gy0 + RPW * wv + r, gx = gx0 + nl;
-            const bool inside = gy < a.Gh && gx < a.Gw;
-            const int oy = gy * mul + oyc, ox = gx * mul + oxc;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
-                f32x4 v = acc[r][f] + b4;
-                if (want_stats && inside) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ssum[f][q] += v[q]; ssq[f][q] += v[q] * v[q]; }
-                }
-                if (inside) {
-                    if (DST == 0) {
-                        if (16 * f + 4 * g < a.Cout) {
-                            h16x4 hv;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) hv[q] = (h16)v[q];
-                            *reinterpret_cast<h16x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g) = hv;
-                        }
-                    } else if (f == 0 && g == 0) {  // NCHW output with <= 4 channels: planes
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (q < a.Cout) {
-                                const float o = a.act == MSTG_ACT_TANH ? tanhf(v[q]) : v[q];
-                                a.y[(((size_t)n * a.Cout + q) * a.Ho + oy) * a.Wo + ox] = (h16)o;
-                            }
-                    }
-                }
-            }
-        }
-    }
-    // ---- statistics of what this tile wrote: per channel, over the tile's pixels ------------------------------------------------
-    if (want_stats) {
-        __syncthreads();  // the patch is no longer needed: reuse LDS for the cross-wave reduction
-        float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][16 * NF]
+        for (int q = 0; q < 4; ++q) ssum[f][q] = ssq[f][q] = 0.f;
+    auto flush_stats = [&](int n_img) {  // call only between tiles (the scratch aliases the patch); ends with a barrier
+        float* red = reinterpret_cast<float*>(patch);  // [4 waves][2][16 * NF]
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -276,13 +318,155 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
                     red[(wv * 2 + 0) * 16 * NF + 16 * f + 4 * g + q] = s1;
                     red[(wv * 2 + 1) * 16 * NF + 16 * f + 4 * g + q] = s2;
                 }
+                ssum[f][q] = ssq[f][q] = 0.f;
             }
         __syncthreads();
         if (tid < 2 * 16 * NF) {
-            const float s = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
-            a.partial[((size_t)n * ntile + t) * 2 * 16 * NF + tid] = s;
+            const float sm = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
+            a.partial[((size_t)n_img * G + blockIdx.x) * 2 * 16 * NF + tid] = sm;
         }
+        __syncthreads();
+    };
+
+    PatchGeom<NPF> Gm;
+    patch_geom<NPF, SRC>(a, p, tid, Gm);
+    PatchRegs<NPF, SRC> R;
+    int it = 0, cur_n = -1;
+    int t = persistent_tile(it, blockIdx.x, G);
+    if (t < total_tiles) patch_fetch<NPF, SRC>(a, p, t, TH, Gm, R);
+    while (t < total_tiles) {
+        const int n = t / ntile, tt = t - n * ntile;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int gy0 = ty * TH, gx0 = tx * F16_TW;
+        if (want_stats && n != cur_n) {
+            if (cur_n >= 0) flush_stats(cur_n);
+            cur_n = n;
+        }
+        if (!(a.dbg & 8)) patch_commit<NPF, SRC>(a, p, n, tid, Gm, R, patch);
+        __syncthreads();
+        const int tnext = persistent_tile(it + 1, blockIdx.x, G);
+        if (tnext < total_tiles && !(a.dbg & 4)) patch_fetch<NPF, SRC>(a, p, tnext, TH, Gm, R);
+
+        for (int cls = 0; cls < ncls; ++cls) {
+            f32x4 acc[RPW][NF];
+            const int4 ci = *reinterpret_cast<const int4*>(smem + 16 * (F16_MAX_STEPS + cls));
+            const int s0 = __builtin_amdgcn_readfirstlane(ci.x), s1 = __builtin_amdgcn_readfirstlane(ci.y);
+            // K-steps as a three-stage pipeline over LDS (all reads return in order, so the waits are counted, never drains):
+            //   table entry of step s+2  |  operand fragments of step s+1 (address from the entry read one stage earlier)  |  MFMAs of s
+            struct StepMeta { unsigned ko, fm; int wi; };
+            auto load_meta = [&](int s) -> StepMeta {
+                StepMeta m;
+                m.ko = *reinterpret_cast<const uint16_t*>(smem + 16 * s + 2 * g);
+                if (NF > 2) {
+                    const unsigned meta = *reinterpret_cast<const unsigned*>(smem + 16 * s + 8);
+                    m.fm = meta & 0xffffu;
+                    m.wi = (int)(meta >> 16);
+                } else {
+                    m.fm = (1u << NF) - 1;
+                    m.wi = s * NF;  // every fragment of every step is stored
+                }
+                return m;
+            };
+            auto load_ops = [&](const StepMeta& m, h16x8 (&bf)[RPW], h16x8 (&af)[NF], unsigned& fm) {
+                fm = NF > 2 ? (unsigned)__builtin_amdgcn_readfirstlane((int)m.fm) : m.fm;
+                int wi = NF > 2 ? __builtin_amdgcn_readfirstlane(m.wi) : m.wi;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    if (SRC == 1) {  // 8-byte pixels: the 16 bytes of a tap pair are only 8-byte aligned -> two 8-byte reads
+                        const h16x4 lo = *reinterpret_cast<const h16x4*>(patch + base[r] + m.ko);
+                        const h16x4 hi = *reinterpret_cast<const h16x4*>(patch + base[r] + m.ko + 8);
+                        bf[r] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    } else {
+                        bf[r] = *reinterpret_cast<const h16x8*>(patch + base[r] + m.ko);
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < NF; ++f)
+                    if (NF <= 2 || ((fm >> f) & 1)) {
+                        if (WLDS) af[f] = *reinterpret_cast<const h16x8*>(wlds_lane + (size_t)wi * 1024);
+                        else af[f] = wglob[(size_t)wi * 64];
+                        ++wi;
+                    }
+            };
+            // first = true: the accumulators start from the bias (MFMA C operand), so no accumulator is ever initialised separately
+            auto mma_step = [&](const h16x8 (&bf)[RPW], const h16x8 (&af)[NF], unsigned fm, auto first) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (NF <= 2 || ((fm >> f) & 1)) {
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+                            acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bf[r], decltype(first)::value ? b4[f] : acc[r][f], 0, 0, 0);
+                    } else if (decltype(first)::value) {
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) acc[r][f] = b4[f];
+                    }
+                }
+            };
+            auto clip = [&](int s) { return s < s1 ? s : s1 - 1; };  // past the end: re-read the last step (loaded, never used)
+            if (a.dbg & 1) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[r][f] = b4[f];
+            } else {
+                h16x8 bA[RPW], aA[NF], bB[RPW], aB[NF];
+                unsigned fmA = 0, fmB = 0;
+                StepMeta m0 = load_meta(s0), m1 = load_meta(clip(s0 + 1));
+                load_ops(m0, bA, aA, fmA);
+                m0 = load_meta(clip(s0 + 2));
+                load_ops(m1, bB, aB, fmB);
+                mma_step(bA, aA, fmA, TrueT{});
+                int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), m0 the table entry of step s + 1
+                for (; s + 1 < s1; s += 2) {
+                    m1 = load_meta(clip(s + 2));
+                    load_ops(m0, bA, aA, fmA);
+                    mma_step(bB, aB, fmB, FalseT{});
+                    m0 = load_meta(clip(s + 3));
+                    load_ops(m1, bB, aB, fmB);
+                    mma_step(bA, aA, fmA, FalseT{});
+                }
+                if (s < s1) mma_step(bB, aB, fmB, FalseT{});
+            }
+            // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) -------
+            const int oyc = up ? __builtin_amdgcn_readfirstlane(ci.z) : 0, oxc = up ? __builtin_amdgcn_readfirstlane(ci.w) : 0, mul = up ? 2 : 1;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int gy = gy0 + RPW * wv + r, gx = gx0 + nl;
+                const bool inside = gy < a.Gh && gx < a.Gw;
+                const int oy = gy * mul + oyc, ox = gx * mul + oxc;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const f32x4 v = acc[r][f];
+                    if (want_stats && inside) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { ssum[f][q] += v[q]; ssq[f][q] += v[q] * v[q]; }
+                    }
+                    if (inside && !(a.dbg & 2)) {
+                        if (DST == 0) {
+                            if (16 * f + 4 * g < a.Cout) {
+                                h16x4 hv;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) hv[q] = (h16)v[q];
+                                *reinterpret_cast<h16x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g) = hv;
+                            }
+                        } else if (f == 0 && g == 0) {  // NCHW output with <= 4 channels: planes
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (q < a.Cout) {
+                                    // tanh(x) = 1 - 2 / (exp(2x) + 1): exact limits at +-inf, ~1e-6 absolute error (the output is fp16)
+                                    const float o = a.act == MSTG_ACT_TANH ? 1.f - 2.f * __frcp_rn(__expf(2.f * v[q]) + 1.f) : v[q];
+                                    a.y[(((size_t)n * a.Cout + q) * a.Ho + oy) * a.Wo + ox] = (h16)o;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the patch
+        ++it;
+        t = tnext;
     }
+    if (want_stats && cur_n >= 0) flush_stats(cur_n);
 }
 
 // partial [N][tiles][2][CP] -> stats [N][C][2] = (mean, rstd); one workgroup per image, double accumulation, fixed order
@@ -365,7 +549,7 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
     }
     if (d->dst_nchw && d->Cout > 4) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: NCHW destination needs <= 4 channels");
     if (!d->dst_nchw && (d->Cout & 3)) return fail_arg(MSTG_E_ALIGN, "f16 conv: NHWC destination needs a multiple of 4 channels");
-    p.pixstride = image_src ? 8 : 2 * Cin + 16;
+    p.pixstride = 0;  // set once the compute stride is known
     p.stride = 1;
     p.up = 0;
     p.ncls = 1;
@@ -454,16 +638,14 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
         delete[] gl;
         return fail_arg(MSTG_E_BADARG, "f16 conv: unknown kind");
     }
+    // LDS pixel stride: conflict-free 16-byte operand reads (ds_read_b128 serves lanes {0-3,12-15,20-27} / {4-11,16-19,28-31} ...
+    // together): for a compute stride of 1 the stride must be 32 mod 64 bytes, for a compute stride of 2 it must be 16 mod 32
+    if (image_src) p.pixstride = 8;
+    else if (p.stride == 1) p.pixstride = ((2 * Cin + 31) / 64) * 64 + 32;
+    else p.pixstride = 2 * Cin + 16;
     // ---- tile height: the tallest of 16 / 8 rows whose patch (plus room for the statistics scratch) fits 64 KiB ----------------
-    const int ext = halo_hi - halo_lo;  // rows / cols beyond (T - 1) * stride + 1
-    int TH = 16;
-    for (;; TH = 8) {
-        p.PH = (TH - 1) * p.stride + 1 + ext;
-        p.PW = (F16_TW - 1) * p.stride + 1 + ext + extra_w;
-        if ((size_t)p.PH * p.PW * p.pixstride <= 64 * 1024 || TH == 8) break;
-    }
-    if ((size_t)p.PH * p.PW * p.pixstride > 160 * 1024) { delete[] gl; return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: patch does not fit LDS"); }
-    p.TH = TH;
+    const int ext0 = halo_hi - halo_lo;  // rows / cols beyond (T - 1) * stride + 1
+    p.PW = (F16_TW - 1) * p.stride + 1 + ext0 + extra_w;  // PH / TH are chosen below, once the filter size is known
     p.oy0 = p.ox0 = halo_lo;
     // ---- four groups per K-step ---------------------------------------------------------------------------------------------
     int s = 0;
@@ -486,25 +668,96 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
                     pt.h[s][k][0] = pt.h[s][k][1] = PackHalf{PK_ZERO, 0, 0, 0, -1};
                 }
             }
-            p.fmask[s] = fm & (uint8_t)((1u << p.NF) - 1);
+            // up to two output fragments: every step feeds both (zero filter rows where a tap has no business), which keeps the
+            // K-loop free of branches and of per-step metadata; four fragments (64-channel MultiScaleBlock): only the live ones
+            p.fmask[s] = p.NF <= 2 ? (uint8_t)((1u << p.NF) - 1) : (uint8_t)(fm & ((1u << p.NF) - 1));
         }
     }
     p.cls_begin[p.ncls] = s;
     p.nsteps = s;
     delete[] gl;
+    // ---- stored filter fragments: only the (step, fragment) pairs some tap feeds ------------------------------------------------
+    int nw = 0;
+    for (int st = 0; st < p.nsteps; ++st) {
+        p.wofs[st] = (uint16_t)nw;
+        for (int f = 0; f < p.NF; ++f)
+            if ((p.fmask[st] >> f) & 1) {
+                pt.pair_step[nw] = (uint8_t)st;
+                pt.pair_frag[nw] = (uint8_t)f;
+                ++nw;
+            }
+    }
+    p.nwfrag = nw;
+    // tile height (16 or 8 rows) and where the filter lives: prefer two workgroups per CU with the filter in LDS (<= 78 KiB each),
+    // then one workgroup with the filter in LDS, then the filter from global memory
+    const int ext = halo_hi - halo_lo;
+    // a candidate height is admissible only if its patch can be prefetched in at most 12 16-byte registers per thread
+    auto patch_bytes_of = [&](int th) {
+        const int ph = (th - 1) * p.stride + 1 + ext;
+        const int elems = image_src ? ph * p.PW : ph * p.PW * (Cin / 8);
+        return cdiv(elems, 256) > 12 ? (size_t)1 << 30 : (size_t)ph * p.PW * p.pixstride;
+    };
+    const size_t wb = (size_t)nw * 1024 + F16_TABLE_BYTES;
+    int TH;
+    if (wb + patch_bytes_of(16) <= 78 * 1024) { TH = 16; p.wlds = 1; }
+    else if (wb + patch_bytes_of(8) <= 78 * 1024) { TH = 8; p.wlds = 1; }
+    else if (wb + patch_bytes_of(16) <= 156 * 1024) { TH = 16; p.wlds = 1; }
+    else if (wb + patch_bytes_of(8) <= 156 * 1024) { TH = 8; p.wlds = 1; }
+    else if (patch_bytes_of(16) + F16_TABLE_BYTES <= 78 * 1024) { TH = 16; p.wlds = 0; }
+    else { TH = 8; p.wlds = 0; }
+    p.TH = TH;
+    p.PH = (TH - 1) * p.stride + 1 + ext;
+    const size_t patch_bytes = patch_bytes_of(TH);
+    if (patch_bytes + F16_TABLE_BYTES > 156 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: patch does not fit LDS");
+    p.m_pw = magic_u32((unsigned)p.PW);
+    const int elems = image_src ? p.PH * p.PW : p.PH * p.PW * (Cin / 8);
+    p.npf = cdiv(elems, 256);
+    if (p.npf > 12) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: patch needs more than 12 prefetch registers per thread");
+    if (p.PH * p.PW >= 65536) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: patch too large");
     return MSTG_OK;
 }
 
-static size_t plan_blob_bytes(const F16Plan& p) { return 256 + (size_t)p.nsteps * p.NF * 64 * 16; }
+static size_t plan_blob_bytes(const F16Plan& p) { return 256 + (size_t)p.nwfrag * 64 * 16; }
 
-template <int RPW, int NF>
-static int launch_conv(const F16ConvArgs& a, const F16Plan& p, int src, int dst, size_t lds, int grid, hipStream_t st) {
-    if (src == 0 && dst == 0) hipLaunchKernelGGL((conv_f16_kernel<RPW, NF, 0, 0>), dim3(grid), dim3(256), lds, st, a, p);
-    else if (src == 1 && dst == 0) hipLaunchKernelGGL((conv_f16_kernel<RPW, NF, 1, 0>), dim3(grid), dim3(256), lds, st, a, p);
-    else if (src == 0 && dst == 1) hipLaunchKernelGGL((conv_f16_kernel<RPW, NF, 0, 1>), dim3(grid), dim3(256), lds, st, a, p);
+template <int RPW, int NF, int NPF>
+static int launch_conv(const F16ConvArgs& a, const F16Plan& p, int src, int dst, size_t lds, long grid /* tiles */, hipStream_t st, int* grid_out) {
+#define MSTG_F16_LAUNCH(SRC, DST)                                                                                          \
+    do {                                                                                                                  \
+        auto kern = p.wlds ? conv_f16_kernel<RPW, NF, SRC, DST, NPF, true> : conv_f16_kernel<RPW, NF, SRC, DST, NPF, false>;      \
+        const void* kptr = reinterpret_cast<const void*>(kern);                                                           \
+        /* persistent workgroups: what the CU really holds (registers, LDS), at most 4, a multiple of 8 in all */       \
+        static const void* c_kern = nullptr;                                                                              \
+        static size_t c_lds = 0;                                                                                          \
+        static int c_occ = 1;                                                                                             \
+        if (c_kern != kptr || c_lds != lds) {                                                                             \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            int nb = 1;                                                                                                   \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kptr, 256, lds) != hipSuccess || nb < 1) nb = 1;        \
+            c_occ = nb > 4 ? 4 : nb;                                                                                      \
+            c_kern = kptr;                                                                                                \
+            c_lds = lds;                                                                                                  \
+        }                                                                                                                 \
+        long g_ = 256L * c_occ;                                                                                           \
+        if (g_ > grid) g_ = (grid + 7) & ~7L;                                                                             \
+        if (a.partial && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)   \
+            return fail_arg(MSTG_E_LAUNCH, "f16 conv: clearing the statistics partials failed");                           \
+        *grid_out = (int)g_;                                                                                              \
+        hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);                                           \
+    } while (0)
+    if (src == 0 && dst == 0) MSTG_F16_LAUNCH(0, 0);
+    else if (src == 1 && dst == 0) MSTG_F16_LAUNCH(1, 0);
+    else if (src == 0 && dst == 1) MSTG_F16_LAUNCH(0, 1);
     else return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: NCHW source and destination in one layer");
+#undef MSTG_F16_LAUNCH
     MSTG_CHECK_LAUNCH("conv_f16_kernel");
     return MSTG_OK;
+}
+
+template <int RPW, int NF>
+static int launch_conv_npf(const F16ConvArgs& a, const F16Plan& p, int src, int dst, size_t lds, long grid, hipStream_t st, int* grid_out) {
+    if (p.npf <= 4) return launch_conv<RPW, NF, 4>(a, p, src, dst, lds, grid, st, grid_out);
+    if (p.npf <= 8) return launch_conv<RPW, NF, 8>(a, p, src, dst, lds, grid, st, grid_out);
+    return launch_conv<RPW, NF, 12>(a, p, src, dst, lds, grid, st, grid_out);
 }
 
 }  // namespace mstg
@@ -534,7 +787,7 @@ extern "C" int mstg_f16_conv_pack(const mstg_f16_conv_desc* d, const float* w0, 
     s.Cin = d->Cin; s.Cout = d->Cout; s.KH = s.KW = d->K; s.c4 = d->kind == 2 ? d->Cin / 4 : 0;
     float* bias = (float*)blob;
     h16* wpk = (h16*)((char*)blob + 256);
-    hipLaunchKernelGGL(f16_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *pt, s, p.nsteps, p.NF, wpk, bias);
+    hipLaunchKernelGGL(f16_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *pt, s, p.nwfrag, p.NF, wpk, bias);
     delete pt;
     MSTG_CHECK_LAUNCH("f16_pack_kernel");
     return MSTG_OK;
@@ -546,8 +799,7 @@ extern "C" size_t mstg_f16_conv_partial_bytes(const mstg_f16_conv_desc* d) {
     const int rc = d ? build_plan(d, p, *pt) : MSTG_E_BADARG;
     delete pt;
     if (rc) return 0;
-    const int Gh = p.up ? d->H : d->Ho, Gw = p.up ? d->W : d->Wo;
-    return (size_t)d->N * cdiv(Gh, p.TH) * cdiv(Gw, F16_TW) * 2 * 16 * p.NF * sizeof(float);
+    return (size_t)d->N * F16_MAX_GRID * 2 * 16 * p.NF * sizeof(float);
 }
 
 extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats, void* y,
@@ -570,31 +822,37 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     a.tiles_y = cdiv(a.Gh, p.TH);
     a.tiles_x = cdiv(a.Gw, F16_TW);
     a.act = d->act;
-    const long grid = (long)a.N * a.tiles_x * a.tiles_y;
-    if (grid > 0x7fffffffL) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: grid too large");
+    { const char* e = getenv("MSTG_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    if (tiles > 0x7fffffffL) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: too many tiles");
     a.partial = nullptr;
     if (out_stats) {
-        const size_t need = (size_t)grid * 2 * 16 * p.NF * sizeof(float);
+        const size_t need = (size_t)a.N * F16_MAX_GRID * 2 * 16 * p.NF * sizeof(float);
         if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "f16 conv: workspace too small for the statistics partials");
         a.partial = (float*)workspace;
     }
     size_t lds = (size_t)p.PH * p.PW * p.pixstride;
     if (lds < (size_t)8 * 16 * p.NF * sizeof(float)) lds = (size_t)8 * 16 * p.NF * sizeof(float);
+    lds = (lds + 15) & ~(size_t)15;
+    if (p.wlds) lds += (size_t)p.nwfrag * 1024;
+    lds += F16_TABLE_BYTES;
+    const long grid = tiles;
+    int launched = 0;
     hipStream_t st = (hipStream_t)stream;
     const int src = d->src_nchw_f32 ? 1 : 0, dst = d->dst_nchw ? 1 : 0;
     int lrc;
     if (p.TH == 16) {
         switch (p.NF) {
-            case 1: lrc = launch_conv<4, 1>(a, p, src, dst, lds, (int)grid, st); break;
-            case 2: lrc = launch_conv<4, 2>(a, p, src, dst, lds, (int)grid, st); break;
-            case 4: lrc = launch_conv<4, 4>(a, p, src, dst, lds, (int)grid, st); break;
+            case 1: lrc = launch_conv_npf<4, 1>(a, p, src, dst, lds, grid, st, &launched); break;
+            case 2: lrc = launch_conv_npf<4, 2>(a, p, src, dst, lds, grid, st, &launched); break;
+            case 4: lrc = launch_conv_npf<4, 4>(a, p, src, dst, lds, grid, st, &launched); break;
             default: return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: output channels must pad to 16, 32 or 64");
         }
     } else {
         switch (p.NF) {
-            case 1: lrc = launch_conv<2, 1>(a, p, src, dst, lds, (int)grid, st); break;
-            case 2: lrc = launch_conv<2, 2>(a, p, src, dst, lds, (int)grid, st); break;
-            case 4: lrc = launch_conv<2, 4>(a, p, src, dst, lds, (int)grid, st); break;
+            case 1: lrc = launch_conv_npf<2, 1>(a, p, src, dst, lds, grid, st, &launched); break;
+            case 2: lrc = launch_conv_npf<2, 2>(a, p, src, dst, lds, grid, st, &launched); break;
+            case 4: lrc = launch_conv_npf<2, 4>(a, p, src, dst, lds, grid, st, &launched); break;
             default: return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: output channels must pad to 16, 32 or 64");
         }
     }
@@ -603,7 +861,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
         const float count = (float)((size_t)d->Ho * d->Wo);
         // ConvTranspose: each compute-grid tile wrote 4 classes; the per-tile sums already cover all of them
         hipLaunchKernelGGL(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats,
-                           a.tiles_x * a.tiles_y, 16 * p.NF, d->Cout, count);
+                           launched, 16 * p.NF, d->Cout, count);
         MSTG_CHECK_LAUNCH("f16_norm_finalize_kernel");
     }
     return MSTG_OK;
@@ -861,7 +1119,7 @@ static int launch_attn_f16(const void* x, const float* in_stats, const void* blo
     const size_t lds = (T::WLDS ? (size_t)T::NFRAG * 64 * 8 : 0) + (size_t)4 * T::END * sizeof(h16);
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid(cdiv(W / 4, 4 * ATT_WPW), H / 4, N);
