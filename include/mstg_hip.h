@@ -131,6 +131,14 @@ int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, size_t n, i
 /* da = gscale[0]*scale * d(mean loss)/da ; db (nullable) = -da */
 int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, size_t n, int kind, const float* gscale, float scale,
                        float* da, float* db, void* stream);
+/* masked-image pre-training loss (pretrain.py:160-162): out[0] = mean(|a * (1 - m) - b * (1 - m)|) and da = gscale[0] * d/da;
+ * a, b, m same shape (m = the 0/1 mask of MonetPhotoDataset).  Workspace as for mstg_loss_mean_fwd. */
+int mstg_masked_l1_mean_fwd(const float* a, const float* b, const float* m, size_t n, float* out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int mstg_masked_l1_mean_bwd(const float* a, const float* b, const float* m, size_t n, const float* gscale, float* da, void* stream);
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) on ONE flat gradient buffer (pretrain.py:165): g *= min(1, max_norm /
+ * (||g||_2 + 1e-6)); norm_out (nullable) receives ||g||_2 before clipping.  Workspace as for mstg_loss_mean_fwd. */
+int mstg_clip_grad_norm(float* g, size_t n, float max_norm, float* norm_out, void* workspace, size_t workspace_bytes, void* stream);
 /* per-channel sum over pixels of an NHWC tensor slice: out[c] = sum_p x[p][coff+c]  (bias gradients, pooling) */
 size_t mstg_channel_sum_workspace_bytes(size_t P, int C);
 int mstg_channel_sum(const float* x, size_t P, int ctot, int coff, int C, float scale, float* out, void* workspace,
@@ -230,6 +238,32 @@ int mstg_f16_attn_pack(const float* wqkv, const float* bqkv, const float* wproj,
                        size_t blob_bytes, void* stream);
 int mstg_f16_attn_fwd(const void* x, const float* in_stats /*nullable*/, const void* blob, void* y, int N, int H, int W, int C,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Image pre/post-processing of the callers either side of the generator, on the device (8-bit RGB, HWC, 3 bytes per pixel).
+ * Replaces PIL / torchvision / numpy work in MonetPhotoDataset (pretrain.py:32-57) and process_cyclegan
+ * (batch_process_images.py:183-233).  Integer work: bit-exact against Pillow.
+ *   filter 0 = BILINEAR (torchvision Resize on a PIL image), 1 = LANCZOS; ksize / coefficient tables follow Pillow's
+ *   Resample.c (precompute_coeffs + normalize_coeffs_8bpc) and are computed on the HOST: kk and bounds are HOST pointers,
+ *   the caller copies the tables to the device and passes the device copies to the two passes below.
+ * ---------------------------------------------------------------------------------------------- */
+int mstg_resample_ksize(int in_size, int out_size, int filter);
+int mstg_resample_coeffs(int in_size, int out_size, int filter, int* kk /* host [out_size][ksize] */, int* bounds /* host [out_size][2] */);
+/* horizontal pass over source rows [y0, y0 + rows): dst (rows, out_w, 3); vertical pass: dst (out_h, w, 3) */
+int mstg_resample_h_u8(const unsigned char* src, unsigned char* dst, int src_w, int y0, int rows, int out_w, int ksize,
+                       const int* kk, const int* bounds, void* stream);
+int mstg_resample_v_u8(const unsigned char* src, unsigned char* dst, int w, int out_h, int ksize, const int* kk, const int* bounds,
+                       void* stream);
+/* dst (dh, dw): filled with `fill` (if >= 0), then the (ch, cw) window of src at (sy0, sx0) pasted at (dy0, dx0): Image.new +
+ * Image.paste (batch_process_images.py:196-199) and Image.crop (:221-233) */
+int mstg_paste_u8(const unsigned char* src, int sh, int sw, int sy0, int sx0, int ch, int cw, unsigned char* dst, int dh, int dw,
+                  int dy0, int dx0, int fill, void* stream);
+/* ToTensor + Normalize(0.5, 0.5) of the (H, W) window at (y0, x0) -> out (3, H, W) fp32, times the 8x8-grid mask (bit i*8+j of
+ * `grid` set = cell kept) when use_mask (pretrain.py:44-57); image_out / mask_out (nullable): unmasked image / the mask */
+int mstg_u8_to_tensor(const unsigned char* src, int sh, int sw, int y0, int x0, int H, int W, float* out, float* image_out,
+                      float* mask_out, unsigned long long grid, int use_mask, void* stream);
+/* (y + 1) / 2 -> clamp(0, 1) -> * 255 -> uint8: y (3, H, W) fp32 -> dst (H, W, 3) (batch_process_images.py:213-217) */
+int mstg_tensor_to_u8(const float* y, int H, int W, unsigned char* dst, void* stream);
 
 #ifdef __cplusplus
 }

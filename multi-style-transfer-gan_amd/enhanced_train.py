@@ -296,3 +296,34 @@ class EnhancedCycleGAN:
             for key, module in pairs:
                 module.load_state_dict(ckpt[key], strict=True)
         return epoch
+
+
+def train(data_root, save_dir, pretrained_path=None, num_epochs=200, batch_size=1, *, channels=16, num_transformer_blocks=1,
+          datasets=None, log_every=10, save_every=20):
+    """The reference's training loop (enhanced_train.py:154-208) on the MI355X step: two ``MonetPhotoDataset`` (transform on the
+    GPU, pretrain.py drop-in), zipped loaders, ``train_step`` per pair, ``save_models`` every 20 epochs.
+
+    Kept from the reference on purpose: the generators see ``batch[0]`` of the dataset triple, i.e. the MASKED image
+    (:184-185 with pretrain.py:56-57).  Different on purpose: ``batch_size`` is honoured (the reference ignores its argument and
+    always uses 1, :167-170 -- the default reproduces that); errors propagate instead of ending training silently (:204-208);
+    losses are read back (one sync) only when they are printed."""
+    from pretrain import DeviceLoader, MonetPhotoDataset, set_seed  # the drop-in module next to this file
+    set_seed(42)
+    model = EnhancedCycleGAN(pretrained_path, channels=channels, num_transformer_blocks=num_transformer_blocks)
+    if datasets is None:
+        datasets = (MonetPhotoDataset(data_root, domain="A", device=model.device), MonetPhotoDataset(data_root, domain="B", device=model.device))
+    monet_loader = DeviceLoader(datasets[0], batch_size=batch_size, shuffle=True, drop_last=True)
+    photo_loader = DeviceLoader(datasets[1], batch_size=batch_size, shuffle=True, drop_last=True)
+    history = []
+    for epoch in range(num_epochs):
+        for i, (monet_batch, photo_batch) in enumerate(zip(monet_loader, photo_loader)):
+            real_A, real_B = monet_batch[0], photo_batch[0]
+            losses = model.train_step_async(real_A, real_B)
+            if (i + 1) % log_every == 0:
+                vals = dict(zip(LOSS_KEYS, losses.tolist()))
+                history.append((epoch, i, vals))
+                print(f"Epoch [{epoch + 1}/{num_epochs}], Step [{i + 1}/{len(monet_loader)}] "
+                      + " ".join(f"{k}: {v:.4f}" for k, v in vals.items()))
+        if (epoch + 1) % save_every == 0:
+            model.save_models(save_dir, epoch + 1)
+    return model, history

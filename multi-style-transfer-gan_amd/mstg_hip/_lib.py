@@ -84,6 +84,16 @@ SIGNATURES = {
     "mstg_f16_attn_plan_bytes": (_sz, [_i]),
     "mstg_f16_attn_pack": (_i, [_fp, _fp, _fp, _fp, _i, _vp, _sz, _vp]),
     "mstg_f16_attn_fwd": (_i, [_vp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mstg_masked_l1_mean_fwd": (_i, [_fp, _fp, _fp, _sz, _fp, _vp, _sz, _vp]),
+    "mstg_masked_l1_mean_bwd": (_i, [_fp, _fp, _fp, _sz, _fp, _fp, _vp]),
+    "mstg_clip_grad_norm": (_i, [_fp, _sz, _f, _fp, _vp, _sz, _vp]),
+    "mstg_resample_ksize": (_i, [_i, _i, _i]),
+    "mstg_resample_coeffs": (_i, [_i, _i, _i, _vp, _vp]),
+    "mstg_resample_h_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mstg_resample_v_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "mstg_paste_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "mstg_u8_to_tensor": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, C.c_ulonglong, _i, _vp]),
+    "mstg_tensor_to_u8": (_i, [_fp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -94,6 +94,51 @@ __global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __rest
     }
 }
 
+
+// masked-image pre-training loss (pretrain.py:160-162): mean(|a * (1 - m) - b * (1 - m)|), products formed first as the reference does
+__global__ void masked_l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ m, size_t n,
+                                         float* __restrict__ partial) {
+    __shared__ float sh[8];
+    float acc = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float w = 1.f - m[i];
+        acc += fabsf(a[i] * w - b[i] * w);
+    }
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ void masked_l1_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ m, size_t n,
+                                     const float* __restrict__ gscale, float* __restrict__ da) {
+    const float gs = (gscale ? gscale[0] : 1.f) / (float)n;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float w = 1.f - m[i];
+        const float d = a[i] * w - b[i] * w;
+        da[i] = (d > 0.f ? gs : (d < 0.f ? -gs : 0.f)) * w;
+    }
+}
+// torch.nn.utils.clip_grad_norm_(max_norm, norm_type=2): g *= min(1, max_norm / (||g|| + 1e-6)); every block re-adds the partial
+// sums of squares in the same fixed order
+__global__ void clip_scale_kernel(float* __restrict__ g, size_t n, const float* __restrict__ partial, int nb, float max_norm,
+                                  float* __restrict__ norm_out) {
+    __shared__ float sh[8];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partial[i];
+    __shared__ float coef_s;
+    const float r = block_sum(acc, sh);
+    if (threadIdx.x == 0) {
+        const float total = sqrtf(r);
+        float c = max_norm / (total + 1e-6f);
+        coef_s = c > 1.f ? 1.f : c;
+        if (blockIdx.x == 0 && norm_out) norm_out[0] = total;
+    }
+    __syncthreads();
+    const float c = coef_s;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) g[i] *= c;
+}
+
 // out[c] = scale * sum_p x[p*ctot + coff + c], two stages: [nb][C] partials then a column sum
 __global__ void channel_sum_partial_kernel(const float* __restrict__ x, size_t P, int ctot, int coff, int C, float* __restrict__ partial) {
     // thread t handles channel t % C for pixels (t / C) + k * (blockDim / C) of this block's pixel range
@@ -254,6 +299,45 @@ extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, 
     MSTG_CHECK_LAUNCH("loss_partial_kernel");
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
     MSTG_CHECK_LAUNCH("loss_final_kernel");
+    return MSTG_OK;
+}
+
+
+extern "C" int mstg_masked_l1_mean_fwd(const float* a, const float* b, const float* m, size_t n, float* out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!a || !b || !m || !out || !workspace) return fail_arg(MSTG_E_BADARG, "masked_l1_fwd: null pointer");
+    if (n == 0) return fail_arg(MSTG_E_BADARG, "masked_l1_fwd: empty tensor");
+    if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "masked_l1_fwd: workspace too small");
+    const int nb = ew_grid(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(masked_l1_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, m, n, (float*)workspace);
+    MSTG_CHECK_LAUNCH("masked_l1_partial_kernel");
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
+    MSTG_CHECK_LAUNCH("loss_final_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_masked_l1_mean_bwd(const float* a, const float* b, const float* m, size_t n, const float* gscale, float* da,
+                                       void* stream) {
+    if (!a || !b || !m || !da) return fail_arg(MSTG_E_BADARG, "masked_l1_bwd: null pointer");
+    if (n == 0) return fail_arg(MSTG_E_BADARG, "masked_l1_bwd: empty tensor");
+    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, m, n, gscale, da);
+    MSTG_CHECK_LAUNCH("masked_l1_bwd_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_clip_grad_norm(float* g, size_t n, float max_norm, float* norm_out, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    if (!g || !workspace) return fail_arg(MSTG_E_BADARG, "clip_grad_norm: null pointer");
+    if (n == 0) return fail_arg(MSTG_E_BADARG, "clip_grad_norm: empty buffer");
+    if (!(max_norm > 0.f)) return fail_arg(MSTG_E_BADARG, "clip_grad_norm: max_norm must be positive");
+    if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "clip_grad_norm: workspace too small");
+    const int nb = ew_grid(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, (const float*)g, (const float*)nullptr, 0.f, n, 1, (float*)workspace);
+    MSTG_CHECK_LAUNCH("loss_partial_kernel");
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, g, n, (const float*)workspace, nb, max_norm, norm_out);
+    MSTG_CHECK_LAUNCH("clip_scale_kernel");
     return MSTG_OK;
 }
 

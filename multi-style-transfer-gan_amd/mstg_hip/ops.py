@@ -556,6 +556,46 @@ def mse_loss(a, b):
     return MeanLossFn.apply(a, b, 0.0, LOSS_MSE)
 
 
+class MaskedL1Fn(torch.autograd.Function):
+    """mean(|gen * (1 - mask) - real * (1 - mask)|): the masked-image pre-training loss (pretrain.py:160-162); gradient to gen only."""
+
+    @staticmethod
+    def forward(ctx, gen, real, mask):
+        lib = _lib.load()
+        gen, real, mask = _req(gen, "generated image"), _req(real, "real image"), _req(mask, "mask")
+        if gen.shape != real.shape or gen.shape != mask.shape:
+            raise RuntimeError("mstg_hip masked_l1: generated image, real image and mask must have one shape")
+        out = torch.empty((), dtype=torch.float32, device=gen.device)
+        ws = _ws(lib.mstg_loss_workspace_bytes(gen.numel()), gen.device)
+        _lib.check(lib.mstg_masked_l1_mean_fwd(_p(gen), _p(real), _p(mask), gen.numel(), _p(out), _p(ws), ws.numel() * 4, _stream()),
+                   "mstg_masked_l1_mean_fwd")
+        ctx.save_for_backward(gen, real, mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gen, real, mask = ctx.saved_tensors
+        g = _req(g, "loss grad_output").reshape(1)
+        da = torch.empty_like(gen)
+        _lib.check(_lib.load().mstg_masked_l1_mean_bwd(_p(gen), _p(real), _p(mask), gen.numel(), _p(g), _p(da), _stream()),
+                   "mstg_masked_l1_mean_bwd")
+        return da, None, None
+
+
+def masked_l1_loss(gen, real, mask):
+    return MaskedL1Fn.apply(gen, real, mask)
+
+
+def clip_grad_norm_flat_(flat_grad: Tensor, max_norm: float) -> Tensor:
+    """clip_grad_norm_ over an optimizer's flat gradient buffer (FlatAdam.grad); returns the pre-clip norm as a 0-dim device tensor."""
+    lib = _lib.load()
+    norm = torch.empty((), dtype=torch.float32, device=flat_grad.device)
+    ws = _ws(lib.mstg_loss_workspace_bytes(flat_grad.numel()), flat_grad.device)
+    _lib.check(lib.mstg_clip_grad_norm(_p(flat_grad), flat_grad.numel(), float(max_norm), _p(norm), _p(ws), ws.numel() * 4, _stream()),
+               "mstg_clip_grad_norm")
+    return norm
+
+
 def mse_to_const(a, value: float):
     """nn.MSELoss()(a, full_like(a, value)) -- the LSGAN targets of enhanced_train.py:72-79,100-101."""
     return MeanLossFn.apply(a, None, float(value), LOSS_MSE)

@@ -1,0 +1,152 @@
+"""Device image pipeline (csrc/image.hip, mstg_hip/image.py) and the loops built on it (pretrain.py, enhanced_train.train), through
+the C ABI.  Integer work is held bit-exact: against Pillow where it is importable (the reference's own dependency for these
+steps), and always against the numpy restatement of Pillow's resampling that tests/test_image_cpu.py pins to Pillow."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import image_ref as IR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mstg_hip import _lib
+    _lib.load()
+
+
+def _img(h, w, seed):
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, 256, size=(h // 4 + 2, w // 4 + 2, 3)).astype(np.uint8)
+    img = np.kron(base, np.ones((4, 4, 1), dtype=np.uint8))[:h, :w]
+    return np.ascontiguousarray((img.astype(np.int32) + rs.randint(-20, 21, size=img.shape)).clip(0, 255).astype(np.uint8))
+
+
+def _pil_or_numpy():
+    try:
+        import PIL  # noqa: F401
+        return IR.pil_resize
+    except ImportError:
+        return IR.resample_numpy
+
+
+@pytest.mark.parametrize("filt", [IR.BILINEAR, IR.LANCZOS])
+@pytest.mark.parametrize("shape,size", [((300, 400), (341, 256)), ((256, 256), (256, 192)), ((97, 301), (256, 82)), ((64, 48), (256, 341)),
+                                        ((500, 333), (170, 256)), ((1200, 900), (192, 256)), ((256, 171), (333, 500))])
+def test_resize_bit_exact(filt, shape, size):
+    from mstg_hip import image as dimg
+    img = _img(shape[0], shape[1], 7)
+    out = dimg.resize_u8(torch.from_numpy(img).to(DEV), size, filt).cpu().numpy()
+    ref = _pil_or_numpy()(img, size, filt)
+    assert out.shape == ref.shape and np.array_equal(out, ref), f"{int((out != ref).sum())} bytes differ"
+
+
+def test_dataset_item_bit_exact_and_mask_stream():
+    """MonetPhotoDataset.__getitem__ on the device: (masked, image, mask) equal the CPU composition bit for bit (ToTensor /
+    Normalize are two fp32 operations per byte), and a seeded run draws the same 64 cells as the reference's loop would."""
+    import pretrain
+    arrays = [_img(300, 420, 3), _img(512, 384, 4), _img(256, 256, 5)]
+    ds = pretrain.MonetPhotoDataset(arrays=arrays, device=DEV)
+    random.seed(42)
+    got = [ds[i] for i in range(3)]
+    rng = random.Random(42)
+    for (masked, image, mask), arr in zip(got, arrays):
+        grid = IR.draw_grid_mask(rng)
+        m_ref, i_ref, k_ref = IR.dataset_item_ref(arr, grid, resize=_pil_or_numpy())
+        assert np.array_equal(image.cpu().numpy(), i_ref)
+        assert np.array_equal(mask.cpu().numpy(), k_ref)
+        assert np.array_equal(masked.cpu().numpy(), m_ref)
+
+
+def test_output_conversion_bit_exact():
+    from mstg_hip import image as dimg
+    y = (torch.randn((3, 96, 160), generator=torch.Generator().manual_seed(1)) * 0.8).clamp(-1.2, 1.2)
+    y[0, 0, :4] = torch.tensor([-1.0, 1.0, 0.0, 0.99999994])
+    out = dimg.to_u8(y.to(DEV)).cpu().numpy()
+    assert np.array_equal(out, IR.output_to_u8(y.numpy()))
+
+
+@pytest.mark.parametrize("shape", [(300, 420), (420, 300), (256, 256), (1100, 1000)])
+def test_process_cyclegan_matches_reference_composition(shape):
+    """process_cyclegan (batch_process_images.py:176-236) end to end on the device with the real generator in the middle: the
+    bytes that reach the model and the bytes that leave equal the PIL / numpy composition, given the same forward."""
+    import enhanced_generator as eg
+    from mstg_hip import image as dimg
+    from oracle import restatement as R
+    m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
+    m.load_state_dict(R.make_state_dict(R.generator_spec(16), 77))
+    m.to(DEV).eval()
+    img = _img(shape[0], shape[1], 11)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = dimg.process_cyclegan(m, torch.from_numpy(img).to(DEV)).cpu().numpy()
+
+        def model_fn(x):  # the SAME forward for the CPU composition: only the pre/post-processing is under test here
+            with torch.no_grad():
+                return m(torch.from_numpy(np.ascontiguousarray(x)).to(DEV)).cpu().numpy()
+        ref = IR.process_cyclegan_ref(model_fn, img, resize=_pil_or_numpy())
+    assert out.shape == ref.shape == ((shape[0], shape[1], 3) if shape[0] * shape[1] <= 1024 * 1024 else out.shape)
+    assert np.array_equal(out, ref), f"{int((out != ref).sum())} of {out.size} bytes differ"
+
+
+def test_masked_l1_and_clip_grad_norm_vs_torch():
+    from mstg_hip import ops
+    g = torch.Generator().manual_seed(2)
+    gen = (torch.rand((2, 3, 64, 64), generator=g) * 2 - 1)
+    real = (torch.rand((2, 3, 64, 64), generator=g) * 2 - 1)
+    mask = (torch.rand((2, 3, 64, 64), generator=g) < 0.6).float()
+    a = gen.to(DEV).requires_grad_(True)
+    loss = ops.masked_l1_loss(a, real.to(DEV), mask.to(DEV))
+    (loss * 3.0).backward()
+    ar = gen.clone().requires_grad_(True)
+    lr = torch.nn.L1Loss()(ar * (1 - mask), real * (1 - mask))
+    (lr * 3.0).backward()
+    assert abs(float(loss) - float(lr)) <= 1e-6 * abs(float(lr))
+    assert torch.allclose(a.grad.cpu(), ar.grad, rtol=0, atol=1e-9)
+    for scale in (0.01, 10.0):
+        flat = (torch.randn(100003, generator=g) * scale)
+        p = torch.nn.Parameter(torch.zeros_like(flat))
+        p.grad = flat.clone()
+        nr = torch.nn.utils.clip_grad_norm_([p], max_norm=1.0)
+        fd = flat.to(DEV)
+        n = ops.clip_grad_norm_flat_(fd, 1.0)
+        assert abs(float(n) - float(nr)) <= 1e-5 * float(nr)
+        assert torch.allclose(fd.cpu(), p.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_pretrain_and_train_loops_run_and_checkpoints_round_trip(tmp_path):
+    """pretrain.train (pretrain.py:99-230) and enhanced_train.train (enhanced_train.py:154-208) on synthetic image arrays: losses
+    finite and moving, checkpoints carry the reference's keys and load back (strict) into fresh modules."""
+    import enhanced_train
+    import plain_generator
+    import pretrain
+    arrays_a = [_img(270 + 3 * i, 300 + 5 * i, 20 + i) for i in range(4)]
+    arrays_b = [_img(300 + 2 * i, 260 + 7 * i, 40 + i) for i in range(4)]
+    ds = (pretrain.MonetPhotoDataset(arrays=arrays_a, device=DEV, img_size=64), pretrain.MonetPhotoDataset(arrays=arrays_b, device=DEV, img_size=64))
+    gen, hist = pretrain.train(None, tmp_path / "pre", num_epochs=50, batch_size=2, channels=8, datasets=ds, log_every=1000)
+    first, last = np.mean([h[2] for h in hist[:4]]), np.mean([h[2] for h in hist[-4:]])
+    assert np.isfinite(first) and np.isfinite(last) and last < first, (first, last)
+    ck = torch.load(tmp_path / "pre" / "generator_pretrain_epoch_50.pth", map_location="cpu", weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "loss"} and ck["epoch"] == 49
+    g2 = plain_generator.Generator(channels=8)
+    g2.load_state_dict(ck["model_state_dict"])
+    for (k, v), (_, v2) in zip(gen.state_dict().items(), g2.state_dict().items()):
+        assert torch.equal(v.cpu(), v2), k
+    ds256 = (pretrain.MonetPhotoDataset(arrays=arrays_a, device=DEV, img_size=64), pretrain.MonetPhotoDataset(arrays=arrays_b, device=DEV, img_size=64))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, hist2 = enhanced_train.train(None, tmp_path / "gan", num_epochs=2, batch_size=2, channels=8, datasets=ds256, log_every=1,
+                                            save_every=2)
+    assert len(hist2) == 4 and all(np.isfinite(v) for _, _, d in hist2 for v in d.values())
+    fresh = enhanced_train.EnhancedCycleGAN(channels=8, num_transformer_blocks=1, device=torch.device(DEV))
+    assert fresh.load_models(tmp_path / "gan", 2) == 2
+    for k, v in model.G_AB.state_dict().items():
+        assert torch.equal(v, fresh.G_AB.state_dict()[k]), k

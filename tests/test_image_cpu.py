@@ -1,0 +1,57 @@
+"""CPU: the image-pipeline oracle (oracle/image_ref.py) against Pillow itself -- the reference's own dependency for these steps
+(pretrain.py:32-57, batch_process_images.py:183-233) -- and the library's host-side coefficient builder against the oracle.
+Integer work: bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import image_ref as IR
+
+PIL = pytest.importorskip("PIL")
+
+
+def _img(h, w, seed):
+    rs = np.random.RandomState(seed)
+    base = rs.randint(0, 256, size=(h // 4 + 2, w // 4 + 2, 3)).astype(np.uint8)  # low-frequency content + noise, like a photo
+    img = np.kron(base, np.ones((4, 4, 1), dtype=np.uint8))[:h, :w]
+    return np.ascontiguousarray((img.astype(np.int32) + rs.randint(-20, 21, size=img.shape)).clip(0, 255).astype(np.uint8))
+
+
+@pytest.mark.parametrize("filt", [IR.BILINEAR, IR.LANCZOS])
+@pytest.mark.parametrize("shape,size", [((300, 400), (341, 256)), ((256, 256), (256, 192)), ((97, 301), (256, 82)), ((64, 48), (256, 341)),
+                                        ((500, 333), (170, 256)), ((256, 171), (333, 500))])
+def test_resample_restatement_matches_pillow(filt, shape, size):
+    img = _img(shape[0], shape[1], 7)
+    assert np.array_equal(IR.resample_numpy(img, size, filt), IR.pil_resize(img, size, filt))
+
+
+def test_library_coefficient_tables_match_restatement():
+    from mstg_hip import _lib, build
+    build.build(verbose=False)
+    lib = _lib.load()
+    for filt in (IR.BILINEAR, IR.LANCZOS):
+        for a, b in ((300, 256), (256, 341), (97, 256), (1024, 256), (256, 256), (171, 500)):
+            ks, kk, bounds = IR.coeffs(a, b, filt)
+            assert lib.mstg_resample_ksize(a, b, filt) == ks
+            kk2, b2 = np.zeros_like(kk), np.zeros_like(bounds)
+            assert lib.mstg_resample_coeffs(a, b, filt, kk2.ctypes.data, b2.ctypes.data) == 0
+            assert np.array_equal(kk, kk2) and np.array_equal(bounds, b2), (filt, a, b)
+
+
+def test_dataset_item_and_output_conversion_restatements():
+    import random
+    img = _img(300, 420, 3)
+    grid = IR.draw_grid_mask(random.Random(42))
+    masked, image, mask = IR.dataset_item_ref(img, grid)
+    m2, i2, k2 = IR.dataset_item_ref(img, grid, resize=IR.resample_numpy)
+    assert np.array_equal(masked, m2) and np.array_equal(image, i2) and np.array_equal(mask, k2)
+    assert masked.shape == (3, 256, 256) and image.min() >= -1 and image.max() <= 1
+    frac = 1.0 - mask.mean()
+    assert 0.15 < frac < 0.65  # 40 % of 64 cells on average
+    y = np.random.RandomState(0).standard_normal((3, 64, 64)).astype(np.float32)
+    u = IR.output_to_u8(y)
+    assert u.dtype == np.uint8 and u.shape == (64, 64, 3) and u.min() == 0 and u.max() == 255
+    out = IR.process_cyclegan_ref(lambda x: -x, img)  # "model" = colour inversion: the geometry must survive the round trip
+    assert out.shape == img.shape
+    assert np.array_equal(out, IR.process_cyclegan_ref(lambda x: -x, img, resize=IR.resample_numpy))
