@@ -35,6 +35,7 @@ extern "C" {
 #define MSTG_ACT_RELU 1
 #define MSTG_ACT_LEAKY02 2 /* LeakyReLU(0.2), enhanced_generator.py:238-251, pretrain.py:67-76 */
 #define MSTG_ACT_TANH 3    /* nn.Tanh, enhanced_generator.py:138 */
+#define MSTG_ACT_GELU 4    /* nn.GELU() (erf form): build-defined StructuralTransformerBlock only */
 
 const char* mstg_version(void);    /* "mstg-hip <semver> gfx950" */
 const char* mstg_arch(void);       /* "gfx950" */
@@ -131,6 +132,8 @@ int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, size_t n, i
 /* da = gscale[0]*scale * d(mean loss)/da ; db (nullable) = -da */
 int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, size_t n, int kind, const float* gscale, float scale,
                        float* da, float* db, void* stream);
+/* y = a + b, n floats (residual connections; 16-byte aligned pointers) */
+int mstg_add(const float* a, const float* b, float* y, size_t n, void* stream);
 /* masked-image pre-training loss (pretrain.py:160-162): out[0] = mean(|a * (1 - m) - b * (1 - m)|) and da = gscale[0] * d/da;
  * a, b, m same shape (m = the 0/1 mask of MonetPhotoDataset).  Workspace as for mstg_loss_mean_fwd. */
 int mstg_masked_l1_mean_fwd(const float* a, const float* b, const float* m, size_t n, float* out, void* workspace,
@@ -264,6 +267,29 @@ int mstg_u8_to_tensor(const unsigned char* src, int sh, int sw, int y0, int x0, 
                       float* mask_out, unsigned long long grid, int use_mask, void* stream);
 /* (y + 1) / 2 -> clamp(0, 1) -> * 255 -> uint8: y (3, H, W) fp32 -> dst (H, W, 3) (batch_process_images.py:213-217) */
 int mstg_tensor_to_u8(const float* y, int H, int W, unsigned char* dst, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BUILD-DEFINED StructuralTransformerBlock pieces.  The reference imports the class from a file its snapshot does not contain
+ * (enhanced_generator.py:4; call shape :115, :218-225) -- parity unpinned; definition in structural_transformer.py.
+ * The block's Linear layers go through mstg_conv2d_* (a Linear over tokens (N, L, dim) is a 1x1 convolution on NHWC).
+ * ---------------------------------------------------------------------------------------------- */
+/* img (N,3,H,W) fp32 -> out (N, H/4, W/4, 4): per 4x4 cell mean R, G, B and mean |dx| + |dy| of the luminance */
+int mstg_structure_map(const float* img, float* out, int N, int H, int W, void* stream);
+/* y = (LayerNorm(x; gamma, beta, eps) ) * (1 + gmod[n]) + bmod[n] over tokens x (N, L, dim); gmod / bmod (N, dim) nullable (plain
+ * LayerNorm); stats (N*L, 2) = (mean, rstd) for the backward.  dim multiple of 4, <= 256. */
+int mstg_ln_mod_fwd(const float* x, const float* gamma, const float* beta, const float* gmod, const float* bmod, float* y,
+                    float* stats, int N, int L, int dim, float eps, void* stream);
+size_t mstg_ln_mod_bwd_workspace_bytes(int N, int L, int dim);
+/* dx, dgamma / dbeta (dim; accumulate != 0: +=), dgmod / dbmod (N, dim; nullable with gmod) */
+int mstg_ln_mod_bwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* gmod, const float* dy,
+                    float* dx, float* dgamma, float* dbeta, float* dgmod, float* dbmod, int accumulate, int N, int L, int dim,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* softmax(q k^T / sqrt(D)) v over all L tokens per image and head: qkv (N, L, 3*heads*D) with q | k | v channel blocks,
+ * out (N, L, heads*D), lse (N, heads, L) = log-sum-exp of the scaled scores (kept for the backward).  D in {8, 16, 32, 64}. */
+int mstg_flash_attn_fwd(const float* qkv, float* out, float* lse, int N, int L, int heads, int D, void* stream);
+/* dqkv from d_out; delta_ws: scratch of N*heads*L floats */
+int mstg_flash_attn_bwd(const float* qkv, const float* out, const float* lse, const float* d_out, float* dqkv, float* delta_ws, int N,
+                        int L, int heads, int D, void* stream);
 
 #ifdef __cplusplus
 }

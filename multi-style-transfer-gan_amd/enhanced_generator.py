@@ -157,8 +157,8 @@ class EnhancedGenerator(nn.Module):
 
     def _style_vector(self, feat_nhwc):
         pooled = ops.spatial_mean(feat_nhwc)  # AdaptiveAvgPool2d(1) + Flatten
-        lin = self.style_encoder[2]
-        return ops.activation(torch.addmm(lin.bias, pooled, lin.weight.t()), ACT_RELU)
+        lin = self.style_encoder[2]        # Linear + ReLU (:144-146) as a 1x1 convolution over N "pixels", ReLU in its epilogue
+        return ops.linear_tokens(pooled, lin.weight, lin.bias, act=ACT_RELU)
 
     def forward_taps(self, x, taps=None):
         """forward() that optionally records stage outputs (NHWC) into ``taps`` -- used by the parity tests."""

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmstg_hip.so")
 
-ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
 LOSS_L1, LOSS_MSE = 0, 1
 
 
@@ -84,9 +84,16 @@ SIGNATURES = {
     "mstg_f16_attn_plan_bytes": (_sz, [_i]),
     "mstg_f16_attn_pack": (_i, [_fp, _fp, _fp, _fp, _i, _vp, _sz, _vp]),
     "mstg_f16_attn_fwd": (_i, [_vp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mstg_add": (_i, [_fp, _fp, _fp, _sz, _vp]),
     "mstg_masked_l1_mean_fwd": (_i, [_fp, _fp, _fp, _sz, _fp, _vp, _sz, _vp]),
     "mstg_masked_l1_mean_bwd": (_i, [_fp, _fp, _fp, _sz, _fp, _fp, _vp]),
     "mstg_clip_grad_norm": (_i, [_fp, _sz, _f, _fp, _vp, _sz, _vp]),
+    "mstg_structure_map": (_i, [_fp, _fp, _i, _i, _i, _vp]),
+    "mstg_ln_mod_fwd": (_i, [_fp] * 7 + [_i, _i, _i, _f, _vp]),
+    "mstg_ln_mod_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mstg_ln_mod_bwd": (_i, [_fp] * 11 + [_i, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_flash_attn_fwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mstg_flash_attn_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_resample_ksize": (_i, [_i, _i, _i]),
     "mstg_resample_coeffs": (_i, [_i, _i, _i, _vp, _vp]),
     "mstg_resample_h_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -58,6 +58,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
         case MSTG_ACT_RELU: return v > 0.f ? v : 0.f;
         case MSTG_ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
         case MSTG_ACT_TANH: return tanhf(v);
+        case MSTG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU() (exact, erf form)
         default: return v;
     }
 }
@@ -67,6 +68,7 @@ __device__ __forceinline__ float act_grad(float v, int act) {
         case MSTG_ACT_RELU: return v > 0.f ? 1.f : 0.f;
         case MSTG_ACT_LEAKY02: return v > 0.f ? 1.f : 0.2f;
         case MSTG_ACT_TANH: return 1.f - v * v;
+        case MSTG_ACT_GELU: return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
         default: return 1.f;
     }
 }

@@ -95,6 +95,14 @@ __global__ void loss_bwd_kernel(const float* __restrict__ a, const float* __rest
 }
 
 
+// y = a + b (residual connections of the build-defined transformer block)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+        reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = a[(n4 << 2) + threadIdx.x] + b[(n4 << 2) + threadIdx.x];
+}
+
 // masked-image pre-training loss (pretrain.py:160-162): mean(|a * (1 - m) - b * (1 - m)|), products formed first as the reference does
 __global__ void masked_l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ m, size_t n,
                                          float* __restrict__ partial) {
@@ -302,6 +310,14 @@ extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, 
     return MSTG_OK;
 }
 
+
+extern "C" int mstg_add(const float* a, const float* b, float* y, size_t n, void* stream) {
+    if (!a || !b || !y) return fail_arg(MSTG_E_BADARG, "add: null pointer");
+    if (n == 0) return MSTG_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(ew_grid((n >> 2) + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, y, n);
+    MSTG_CHECK_LAUNCH("add_kernel");
+    return MSTG_OK;
+}
 
 extern "C" int mstg_masked_l1_mean_fwd(const float* a, const float* b, const float* m, size_t n, float* out, void* workspace,
                                        size_t workspace_bytes, void* stream) {

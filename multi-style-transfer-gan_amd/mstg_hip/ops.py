@@ -15,7 +15,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH, LOSS_L1, LOSS_MSE, ConvDesc  # noqa: F401
+from ._lib import ACT_GELU, ACT_LEAKY02, ACT_NONE, ACT_RELU, ACT_TANH, LOSS_L1, LOSS_MSE, ConvDesc  # noqa: F401
 
 Tensor = torch.Tensor
 
@@ -751,6 +751,131 @@ def install_fused_spectral_norm(module, name: str = "weight") -> bool:
             module.register_forward_pre_hook(pre)
             return True
     return False
+
+
+# ----------------------------------------------------------------------------------------------------------
+# build-defined StructuralTransformerBlock pieces (parity unpinned; see structural_transformer.py)
+# ----------------------------------------------------------------------------------------------------------
+def structure_map(img: Tensor) -> Tensor:
+    """(N,3,H,W) image -> (N, H/4, W/4, 4) structure features; treated as a constant (no gradient)."""
+    img = _req(img.detach(), "structure-map image")
+    N, _, H, W = img.shape
+    out = torch.empty((N, H // 4, W // 4, 4), dtype=torch.float32, device=img.device)
+    _lib.check(_lib.load().mstg_structure_map(_p(img), _p(out), N, H, W, _stream()), "mstg_structure_map")
+    return out
+
+
+class LayerNormModFn(torch.autograd.Function):
+    """y = (LayerNorm(x; gamma, beta) ) * (1 + gmod[n]) + bmod[n]; x (N, L, dim), gmod / bmod (N, dim) or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, gmod, bmod, eps):
+        lib = _lib.load()
+        x, gamma, beta = _req(x, "layer-norm input"), _req(gamma, "layer-norm weight"), _req(beta, "layer-norm bias")
+        gmod = None if gmod is None else _req(gmod, "modulation scale")
+        bmod = None if bmod is None else _req(bmod, "modulation shift")
+        N, L, dim = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((N * L, 2), dtype=torch.float32, device=x.device)
+        _timed("ln_mod_fwd_kernel", 0, 4.0 * 2 * x.numel(), lambda: _lib.check(
+            lib.mstg_ln_mod_fwd(_p(x), _p(gamma), _p(beta), _p(gmod), _p(bmod), _p(y), _p(stats), N, L, dim, float(eps), _stream()),
+            "mstg_ln_mod_fwd"))
+        ctx.prefs = (gamma, beta)
+        ctx.has_mod = gmod is not None
+        ctx.save_for_backward(x, stats, gamma, beta, gmod)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, gamma, beta, gmod = ctx.saved_tensors
+        dy = _req(dy, "layer-norm grad_output")
+        N, L, dim = x.shape
+        dx = torch.empty_like(x)
+        sg, sb = _grad_slot(ctx.prefs[0]), _grad_slot(ctx.prefs[1])
+        direct = sg is not None and sb is not None
+        dgamma = sg if direct else torch.empty_like(gamma)
+        dbeta = sb if direct else torch.empty_like(beta)
+        dgm = torch.empty((N, dim), dtype=torch.float32, device=x.device) if ctx.has_mod else None
+        dbm = torch.empty((N, dim), dtype=torch.float32, device=x.device) if ctx.has_mod else None
+        ws = _ws(lib.mstg_ln_mod_bwd_workspace_bytes(N, L, dim), x.device)
+        _timed("ln_mod_bwd_kernel", 0, 4.0 * 3 * x.numel(), lambda: _lib.check(
+            lib.mstg_ln_mod_bwd(_p(x), _p(stats), _p(gamma), _p(beta), _p(gmod), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(dgm), _p(dbm),
+                                int(direct), N, L, dim, _p(ws), ws.numel() * 4, _stream()), "mstg_ln_mod_bwd"))
+        return dx, (None if direct else dgamma), (None if direct else dbeta), dgm, dbm, None
+
+
+def layer_norm_mod(x, gamma, beta, gmod=None, bmod=None, eps=1e-5):
+    return LayerNormModFn.apply(x, gamma, beta, gmod, bmod, eps)
+
+
+class FlashAttnFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(D)) v over all tokens of an image, per head; qkv (N, L, 3*heads*D) -> (N, L, heads*D)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = _req(qkv, "attention qkv")
+        N, L, C3 = qkv.shape
+        dim = C3 // 3
+        D = dim // heads
+        if dim * 3 != C3 or D * heads != dim:
+            raise RuntimeError(f"mstg_hip flash attention: {C3} channels do not split into q|k|v x {heads} heads")
+        out = torch.empty((N, L, dim), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((N, heads, L), dtype=torch.float32, device=qkv.device)
+        _timed(f"flash_fwd_kernel<{D}>", 4.0 * N * heads * L * L * D, 4.0 * (qkv.numel() + out.numel()), lambda: _lib.check(
+            _lib.load().mstg_flash_attn_fwd(_p(qkv), _p(out), _p(lse), N, L, heads, D, _stream()), "mstg_flash_attn_fwd"),
+            f"N{N} L{L} heads{heads} D{D}")
+        ctx.heads = heads
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        qkv, out, lse = ctx.saved_tensors
+        d_out = _req(d_out, "attention grad_output")
+        N, L, C3 = qkv.shape
+        heads = ctx.heads
+        D = C3 // 3 // heads
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty((N, heads, L), dtype=torch.float32, device=qkv.device)
+        _timed(f"flash_bwd_kernels<{D}>", 10.0 * N * heads * L * L * D, 4.0 * (2 * qkv.numel() + 2 * out.numel()), lambda: _lib.check(
+            _lib.load().mstg_flash_attn_bwd(_p(qkv), _p(out), _p(lse), _p(d_out), _p(dqkv), _p(delta), N, L, heads, D, _stream()),
+            "mstg_flash_attn_bwd"), f"N{N} L{L} heads{heads} D{D}")
+        return dqkv, None
+
+
+def flash_attention(qkv, heads):
+    return FlashAttnFn.apply(qkv, heads)
+
+
+class AddFn(torch.autograd.Function):
+    """y = a + b on the HIP element-wise kernel (same shapes)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _req(a, "add lhs"), _req(b, "add rhs")
+        if a.shape != b.shape:
+            raise RuntimeError(f"mstg_hip add: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+        y = torch.empty_like(a)
+        _lib.check(_lib.load().mstg_add(_p(a), _p(b), _p(y), a.numel(), _stream()), "mstg_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+def linear_tokens(x, weight, bias, act=ACT_NONE):
+    """nn.Linear over the last dimension of (N, L, Cin) tokens (or (N, Cin) vectors) = a 1x1 convolution on an NHWC view: runs on
+    the implicit-GEMM kernels with their weight / bias gradients; `weight` (Cout, Cin) as nn.Linear stores it."""
+    squeeze = x.dim() == 2
+    x4 = x.reshape(x.shape[0], 1, -1 if not squeeze else 1, x.shape[-1]) if not squeeze else x.reshape(x.shape[0], 1, 1, x.shape[-1])
+    y = conv2d(x4, weight.view(weight.shape[0], weight.shape[1], 1, 1), bias, 1, act=act)
+    return y.reshape(*x.shape[:-1], weight.shape[0])
 
 
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, mask=None):

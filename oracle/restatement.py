@@ -13,7 +13,7 @@ in the build container (<=1e-5), and the resulting vectors are committed as
 fixtures so the check can be repeated without the reference.
 
 Not pinned ("parity unpinned"): ``gram_matrix`` / ``vgg_features`` /
-``multi_style_gram_loss`` / ``structural_transformer_block`` -- the reference has no
+``multi_style_gram_loss`` / ``structural_transformer_block`` / ``structure_map`` -- the reference has no
 implementation of them; they restate the build's own definition.
 
 Reference sites (relative to /root/reference):
@@ -197,16 +197,25 @@ def _stage(x: Tensor, sd: SD, name: str, transpose: bool) -> Tensor:
     return multi_scale_block(x, sd, name + ".4")
 
 
-def generator_forward(sd: SD, x: Tensor, taps: Optional[dict] = None) -> Tensor:
-    """EnhancedGenerator(num_transformer_blocks=0).forward, enhanced_generator.py:210-228.
+def generator_forward(sd: SD, x: Tensor, taps: Optional[dict] = None, num_blocks: int = 0, num_heads: int = 4) -> Tensor:
+    """EnhancedGenerator.forward, enhanced_generator.py:210-228.
 
     ``taps`` (optional dict) receives initial/down1/down2/up1/up2/pre_tanh/out.
-    The style encoder (:216) is dead code when there are no transformer blocks and is skipped.
+    With ``num_blocks`` = 0 (the parity-pinned configuration) the style encoder (:216) is dead code and is skipped; with blocks the
+    token path of :216-225 runs through the BUILD-DEFINED ``structural_transformer_block`` (parity unpinned).
     """
     h = F.relu(instance_norm(F.conv2d(x, sd["initial.0.weight"], sd["initial.0.bias"], padding=3)))
     t = {"initial": h}
     h = _stage(h, sd, "down1", False); t["down1"] = h
     h = _stage(h, sd, "down2", False); t["down2"] = h
+    if num_blocks:
+        style = style_encoder(sd, h)                                  # :216
+        B, Cn, H4, W4 = h.shape
+        tokens = h.flatten(2).transpose(1, 2)                         # :218-219
+        for i in range(num_blocks):
+            tokens = structural_transformer_block(sd, f"transformer_blocks.{i}", tokens, style, x, num_heads)   # :222-223
+        h = tokens.transpose(1, 2).reshape(B, Cn, H4, W4)             # :225
+        t["tokens"] = h
     h = _stage(h, sd, "up1", True); t["up1"] = h
     h = _stage(h, sd, "up2", True); t["up2"] = h
     pre = F.conv2d(h, sd["output.0.weight"], sd["output.0.bias"], padding=3)
@@ -375,6 +384,57 @@ class CycleGANOracle:
 # --------------------------------------------------------------------------------------
 # build-defined extensions -- PARITY UNPINNED (no reference implementation)
 # --------------------------------------------------------------------------------------
+def transformer_block_spec(dim: int, prefix: str = "transformer_blocks.0", mlp_ratio: int = 2):
+    """state_dict keys/shapes of the build-defined StructuralTransformerBlock(dim) (structural_transformer.py)."""
+    return [(f"{prefix}.struct_proj.weight", (dim, 4)), (f"{prefix}.struct_proj.bias", (dim,)),
+            (f"{prefix}.style_mod.weight", (2 * dim, dim)), (f"{prefix}.style_mod.bias", (2 * dim,)),
+            (f"{prefix}.norm1.weight", (dim,)), (f"{prefix}.norm1.bias", (dim,)),
+            (f"{prefix}.qkv.weight", (3 * dim, dim)), (f"{prefix}.qkv.bias", (3 * dim,)),
+            (f"{prefix}.proj.weight", (dim, dim)), (f"{prefix}.proj.bias", (dim,)),
+            (f"{prefix}.norm2.weight", (dim,)), (f"{prefix}.norm2.bias", (dim,)),
+            (f"{prefix}.fc1.weight", (mlp_ratio * dim, dim)), (f"{prefix}.fc1.bias", (mlp_ratio * dim,)),
+            (f"{prefix}.fc2.weight", (dim, mlp_ratio * dim)), (f"{prefix}.fc2.bias", (dim,))]
+
+
+def generator_spec_with_blocks(C: int, num_blocks: int = 1):
+    """EnhancedGenerator(C, num_transformer_blocks=num_blocks).state_dict() key order (blocks sit after down2 in module order)."""
+    spec = generator_spec(C)
+    idx = next(i for i, (k, _) in enumerate(spec) if k.startswith("up1."))
+    blocks = []
+    for i in range(num_blocks):
+        blocks += transformer_block_spec(4 * C, f"transformer_blocks.{i}")
+    return spec[:idx] + blocks + spec[idx:]
+
+
+def structure_map(img: Tensor) -> Tensor:
+    """(N,3,H,W) -> (N, L, 4): per 4x4 cell mean R, G, B and mean of |dx| + |dy| of the luminance (forward differences, zero
+    across the image border)."""
+    lum = 0.299 * img[:, 0] + 0.587 * img[:, 1] + 0.114 * img[:, 2]
+    gx = torch.zeros_like(lum)
+    gy = torch.zeros_like(lum)
+    gx[:, :, :-1] = lum[:, :, 1:] - lum[:, :, :-1]
+    gy[:, :-1, :] = lum[:, 1:, :] - lum[:, :-1, :]
+    feats = torch.cat([img, (gx.abs() + gy.abs()).unsqueeze(1)], dim=1)
+    return F.avg_pool2d(feats, 4).flatten(2).transpose(1, 2)
+
+
+def structural_transformer_block(sd: SD, p: str, x: Tensor, style: Tensor, orig: Tensor, num_heads: int = 4) -> Tensor:
+    """The build's definition of StructuralTransformerBlock.forward (structural_transformer.py docstring), plain torch ops."""
+    N, L, dim = x.shape
+    d = dim // num_heads
+    with torch.no_grad():
+        s = structure_map(orig)
+    h = x + F.linear(s.to(x.dtype), sd[p + ".struct_proj.weight"], sd[p + ".struct_proj.bias"])
+    g, b = F.linear(style, sd[p + ".style_mod.weight"], sd[p + ".style_mod.bias"]).chunk(2, dim=-1)
+    u = F.layer_norm(h, (dim,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5) * (1 + g[:, None, :]) + b[:, None, :]
+    qkv = F.linear(u, sd[p + ".qkv.weight"], sd[p + ".qkv.bias"])
+    q, k, v = (t.reshape(N, L, num_heads, d).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+    a = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), dim=-1) @ v
+    h = h + F.linear(a.transpose(1, 2).reshape(N, L, dim), sd[p + ".proj.weight"], sd[p + ".proj.bias"])
+    m = F.gelu(F.linear(F.layer_norm(h, (dim,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5), sd[p + ".fc1.weight"], sd[p + ".fc1.bias"]))
+    return h + F.linear(m, sd[p + ".fc2.weight"], sd[p + ".fc2.bias"])
+
+
 VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512]  # VGG16 up to relu4_3
 VGG_TAPS = (1, 3, 6, 9)  # conv indices whose ReLU output is tapped: relu1_2, relu2_2, relu3_3, relu4_3
 

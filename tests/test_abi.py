@@ -78,7 +78,10 @@ def test_module_surface_and_state_dict_keys():
     g = eg.EnhancedGenerator()  # reference defaults: channels=64, num_transformer_blocks=3
     assert len(g.transformer_blocks) == 3 and g.initial[0].weight.shape == (64, 3, 7, 7)
     g1 = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)  # what every reference caller builds
-    assert sum(p.numel() for p in g1.parameters()) == 168611 + 0  # SURVEY.md a1 (identity block owns no parameters)
+    block = sum(p.numel() for p in g1.transformer_blocks.parameters())
+    assert block == sum(int(torch.tensor(s_).prod()) for _, s_ in R.transformer_block_spec(64)) > 0  # build-defined block (F1)
+    assert sum(p.numel() for p in g1.parameters()) == 168611 + block  # SURVEY.md a1 for everything the reference defines
+    assert [(k, tuple(v.shape)) for k, v in g1.state_dict().items()] == R.generator_spec_with_blocks(16, 1)
     g1.gradient_checkpointing_enable()
     assert g1.use_checkpointing
     for name in ("LocalAttention", "MultiScaleBlock", "EnhancedGenerator", "EnhancedDiscriminator"):

@@ -80,7 +80,7 @@ def test_process_cyclegan_matches_reference_composition(shape):
     from mstg_hip import image as dimg
     from oracle import restatement as R
     m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
-    m.load_state_dict(R.make_state_dict(R.generator_spec(16), 77))
+    m.load_state_dict(R.make_state_dict(R.generator_spec_with_blocks(16, 1), 77))
     m.to(DEV).eval()
     img = _img(shape[0], shape[1], 11)
     import warnings

@@ -161,17 +161,14 @@ def test_generator_no_grad_blocks1_eval_and_errors():
     """What the inference callers do: num_transformer_blocks=1, .eval(), torch.no_grad() (direct_transform.py:35-63)."""
     import enhanced_generator as eg
     from oracle import restatement as R
-    sd = R.make_state_dict(R.generator_spec(16), 7)
+    sd = R.make_state_dict(R.generator_spec_with_blocks(16, 1), 7)
     m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
-    m.load_state_dict(sd)  # identity block owns no keys -> strict load works
+    m.load_state_dict(sd)  # strict, build-defined block included
     m.to(DEV).eval()
     x = R.make_input((1, 3, 128, 128), 8)
     with torch.no_grad():
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            y = m(x.to(DEV))
-        yr = R.generator_forward(sd, x)
+        y = m(x.to(DEV))
+        yr = R.generator_forward(sd, x, num_blocks=1)
     report("G blocks=1 eval 128x128 vs oracle", rel_l2(y, yr), 1e-4)
     assert y.shape == (1, 3, 128, 128) and float(y.abs().max()) <= 1.0
     for bad in ((1, 3, 250, 250), (1, 3, 248, 248), (1, 3, 128, 136 + 4)):
