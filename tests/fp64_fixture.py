@@ -51,6 +51,10 @@ class Fp64TrainStepFixture:
         """(per-tensor distances of the reference's own teacher-forced fp32 run from fp64 [-1 = no gradient], aggregate over live tensors)"""
         return [float(v) for v in self.g[f"{which}32_dist_{k}"]], float(self.g[f"{which}32_agg_{k}"])
 
+    def scan(self, which="g"):
+        """the reference's own teacher-forced fp32-vs-fp64 aggregate gradient distances over many draws of this shape (sorted)"""
+        return np.sort(np.asarray(self.g[f"scan_{which}32_agg"], dtype=np.float64))
+
     def uv(self, k):
         """{'D_A.main.0.weight_u': tensor, ...}: spectral-norm vectors step k starts from"""
         pre = f"uv_{k}_"
