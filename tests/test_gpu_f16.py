@@ -231,3 +231,38 @@ def test_config5_forward_1024_fp16():
     assert torch.isfinite(y).all()
     report("config5 fp16 sample 0 of batch 64 vs batch 1", rel_l2(y[0:1].float(), y1.float()), 1e-3)
     report("config5 fp16 sample 63 of batch 64 vs batch 1", rel_l2(y[63:64].float(), y63.float()), 1e-3)
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_graph_inference_matches_eager(half):
+    """hipGraph replay of the inference forward (BASELINE config #1 is launch-bound at batch 1): bit-identical to the eager
+    forward, follows a load_state_dict, and a second shape gets its own graph."""
+    import time
+    from oracle import restatement as R
+    m, sd = _pair(431)
+    if half:
+        m.half_inference()
+    x = R.make_input((1, 3, 256, 256), 432).to(DEV)
+    x2 = R.make_input((2, 3, 64, 80), 433).to(DEV)
+    with torch.no_grad():
+        y_eager, y2_eager = m(x), m(x2)
+        m.graph_inference()
+        y_graph, y2_graph = m(x), m(x2)
+        assert torch.equal(y_eager, y_graph) and torch.equal(y2_eager, y2_graph)
+        assert torch.equal(m(x), y_eager)  # replay
+        m.load_state_dict(R.make_state_dict(R.generator_spec(16), 434))
+        y_new = m(x)
+        m.graph_inference(False)
+        assert torch.equal(y_new, m(x)) and not torch.equal(y_new, y_eager)
+        # latency (informational)
+        for mode in (False, True):
+            m.graph_inference(mode)
+            for _ in range(3):
+                m(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                m(x)
+            torch.cuda.synchronize()
+            print(f"  [latency] 256x256 batch 1 {'fp16' if half else 'fp32'} {'hipGraph' if mode else 'eager   '}: "
+                  f"{(time.perf_counter() - t0) / 50 * 1e3:.3f} ms")
