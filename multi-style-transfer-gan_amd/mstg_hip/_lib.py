@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmstg_hip.so")
+LIB_PATH = os.environ.get("MSTG_LIB") or os.path.join(HERE, "libmstg_hip.so")  # MSTG_LIB: A/B of two builds in one GPU call
 
 ACT_NONE, ACT_RELU, ACT_LEAKY02, ACT_TANH, ACT_GELU = 0, 1, 2, 3, 4
 LOSS_L1, LOSS_MSE = 0, 1

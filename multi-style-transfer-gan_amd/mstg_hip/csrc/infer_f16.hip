@@ -27,9 +27,10 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 namespace mstg {
 
 constexpr int F16_MAX_STEPS = 64;
+constexpr int F16_MAX_SEG = 8;
 constexpr int F16_TW = 16;  // tile width in output pixels of the compute grid (= one MFMA N fragment)
 constexpr int F16_MAX_GRID = 1024;  // persistent workgroups: 256 CUs x at most 4
-constexpr int F16_TABLE_BYTES = (64 + 4) * 16;  // K-step table + class table at the start of the kernel's LDS
+constexpr int F16_TABLE_BYTES = (64 + F16_MAX_SEG) * 16;  // K-step table + segment table at the start of the kernel's LDS
 
 // how the pack kernel fills one half (4 k-elements) of a lane group
 enum : int8_t { PK_ZERO = 0, PK_CONV = 1, PK_CONVT = 2, PK_MS_CENTER = 3, PK_MS_RING1 = 4 /* +0,1,2 = branches 2,3,4 */ };
@@ -42,11 +43,16 @@ struct PackTable {
 struct F16Plan {
     int nsteps, ncls;
     int cls_begin[5];
+    // segments: runs of K-steps that feed the same set of output fragments; a class (ConvTranspose parity, or the whole layer)
+    // is a run of segments that share accumulators: `first` starts them from the bias, `last` runs the epilogue
+    int nseg;
+    struct Seg { int16_t s0, s1; uint8_t mask, first, last, cls; int wbase; } seg[F16_MAX_SEG];
     uint16_t koff[F16_MAX_STEPS][4];  // byte offset of the group's 16 bytes relative to the lane's pixel base in the patch
     uint8_t fmask[F16_MAX_STEPS];     // output-channel fragments the step feeds
     uint16_t wofs[F16_MAX_STEPS];     // index of the step's first stored filter fragment (only the fragments in fmask are stored)
     int nwfrag, wlds;                 // stored fragments in all; 1: the kernel keeps the filter in LDS
     unsigned m_pw;                    // magic multiplier for division by PW
+    unsigned m_ntile, m_tx;           // ... by tiles per image and by tiles per row (exact while t * d < 2^32: checked by the host)
     int npf;                          // 16-byte patch elements per thread
     int8_t cls_oy[4], cls_ox[4];      // ConvTranspose: output parity of the class
     int PH, PW, pixstride;            // patch rows / cols / bytes per pixel
@@ -132,6 +138,7 @@ __global__ void f16_pack_kernel(PackTable t, PackSrc s, int nwfrag, int NF, h16*
 //     K-steps (operands of step s+1 are read while the MFMAs of step s run) | epilogue: bias, statistics, store | barrier
 // so the global round trip of a patch hides behind the previous tile's arithmetic.
 // -------------------------------------------------------------------------------------------------------------------------
+template <unsigned M> struct MaskT { static constexpr unsigned value = M; };
 struct TrueT { static constexpr bool value = true; };
 struct FalseT { static constexpr bool value = false; };
 
@@ -148,8 +155,6 @@ struct PatchRegs {
 template <int NPF>
 struct PatchGeom {
     unsigned rel[NPF];   // byte offset in the source image relative to the patch origin (SRC 1: within one plane)
-    unsigned dst[NPF];   // LDS byte offset
-    unsigned rc[NPF];    // r << 16 | c
     unsigned vmask;      // element exists
 };
 
@@ -164,13 +169,10 @@ __device__ __forceinline__ void patch_geom(const F16ConvArgs& a, const F16Plan& 
         const int pix = e >> sh;
         const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
         if (e < total) Gm.vmask |= 1u << k;
-        Gm.rc[k] = ((unsigned)r << 16) | (unsigned)c;
         if (SRC == 0) {
             Gm.rel[k] = (unsigned)(((r * a.W + c) * a.Cin + 8 * o) * 2);
-            Gm.dst[k] = (unsigned)(pix * p.pixstride + 16 * o);
         } else {
             Gm.rel[k] = (unsigned)((r * a.W + c) * 4);
-            Gm.dst[k] = (unsigned)(pix * 8);
         }
     }
 }
@@ -179,11 +181,11 @@ __device__ __forceinline__ void patch_geom(const F16ConvArgs& a, const F16Plan& 
 __device__ __forceinline__ int persistent_tile(int it, int b, int G) { return it * G + (b & 7) * (G >> 3) + (b >> 3); }
 
 template <int NPF, int SRC>
-__device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan& p, int t, int TH, const PatchGeom<NPF>& Gm,
+__device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan& p, int t, int TH, int tid, const PatchGeom<NPF>& Gm,
                                             PatchRegs<NPF, SRC>& R) {
     const int ntile = a.tiles_x * a.tiles_y;
-    const int n = t / ntile, tt = t - n * ntile;
-    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+    const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
     const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * F16_TW * p.stride + p.ox0;
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + p.PH <= a.H && sx0 + p.PW <= a.W;  // uniform
     if (SRC == 0) {
@@ -196,9 +198,12 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
         } else {
             R.okmask = 0;
             const long org = ((long)sy0 * a.W + sx0) * a.Cin * 2;
+            const int oct = a.Cin >> 3, sh = oct == 2 ? 1 : (oct == 4 ? 2 : 3);
 #pragma unroll
-            for (int k = 0; k < NPF; ++k) {
-                const int iy = sy0 + (int)(Gm.rc[k] >> 16), ix = sx0 + (int)(Gm.rc[k] & 0xffffu);
+            for (int k = 0; k < NPF; ++k) {  // border tile (rare): recompute (r, c) instead of keeping them in registers
+                const int pix = (256 * k + tid) >> sh;
+                const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
+                const int iy = sy0 + r, ix = sx0 + c;
                 const bool ok = ((Gm.vmask >> k) & 1) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 R.okmask |= (unsigned)ok << k;
                 R.v[k] = *reinterpret_cast<const h16x8*>(img + (ok ? org + (long)Gm.rel[k] : 0L));
@@ -211,7 +216,9 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
         const long org = ((long)sy0 * a.W + sx0) * 4;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            const int iy = sy0 + (int)(Gm.rc[k] >> 16), ix = sx0 + (int)(Gm.rc[k] & 0xffffu);
+            const int e = 256 * k + tid;
+            const int r = (int)__umulhi((unsigned)e, p.m_pw), c = e - r * p.PW;
+            const int iy = sy0 + r, ix = sx0 + c;
             const bool ok = ((Gm.vmask >> k) & 1) && (interior || ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W));
             R.okmask |= (unsigned)ok << k;
             const char* q = img + (ok ? org + (long)Gm.rel[k] : 0L);
@@ -229,7 +236,7 @@ template <int NPF, int SRC>
 __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan& p, int n, int tid, const PatchGeom<NPF>& Gm,
                                              const PatchRegs<NPF, SRC>& R, unsigned char* patch) {
     if (SRC == 0) {
-        const int oct = a.Cin >> 3, o = tid & (oct - 1);
+        const int oct = a.Cin >> 3, o = tid & (oct - 1), sh = oct == 2 ? 1 : (oct == 4 ? 2 : 3);
         const bool norm = a.in_stats != nullptr;
         float sc[8], nb[8];  // (x - mean) * rstd = x * sc + nb
         if (norm) {
@@ -246,7 +253,7 @@ __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan
                     for (int c = 0; c < 8; ++c) w[c] = (h16)fmaxf(fmaf((float)w[c], sc[c], nb[c]), 0.f);
                 }
                 if (!((R.okmask >> k) & 1)) w = h16x8{0, 0, 0, 0, 0, 0, 0, 0};  // zero padding applies to the NORMALISED activation
-                *reinterpret_cast<h16x8*>(patch + Gm.dst[k]) = w;
+                *reinterpret_cast<h16x8*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;
             }
         }
     } else {
@@ -256,12 +263,13 @@ __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan
                 h16x4 w;
 #pragma unroll
                 for (int ch = 0; ch < 4; ++ch) w[ch] = ((R.okmask >> k) & 1) ? (h16)R.f[k][ch] : (h16)0;
-                *reinterpret_cast<h16x4*>(patch + Gm.dst[k]) = w;
+                *reinterpret_cast<h16x4*>(patch + (unsigned)((256 * k + tid) * 8)) = w;
             }
         }
     }
 }
 
+// register budget: the light single-fragment kernels want four workgroups per CU (<= 128 VGPRs); the others are LDS-bound to 1-2
 template <int RPW, int NF, int SRC, int DST, int NPF, bool WLDS>
 __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -278,11 +286,13 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
     if (tid < F16_MAX_STEPS) {
         uint16_t* e = reinterpret_cast<uint16_t*>(smem + 16 * tid);
         e[0] = p.koff[tid][0]; e[1] = p.koff[tid][1]; e[2] = p.koff[tid][2]; e[3] = p.koff[tid][3];
-        e[4] = p.fmask[tid]; e[5] = p.wofs[tid];
-    } else if (tid < F16_MAX_STEPS + 4) {
+    } else if (tid < F16_MAX_STEPS + F16_MAX_SEG) {
         const int c = tid - F16_MAX_STEPS;
         int* e = reinterpret_cast<int*>(smem + 16 * tid);
-        e[0] = p.cls_begin[c]; e[1] = p.cls_begin[c + 1]; e[2] = p.cls_oy[c]; e[3] = p.cls_ox[c];
+        const int cl = p.seg[c].cls;
+        e[0] = p.seg[c].s0; e[1] = p.seg[c].s1;
+        e[2] = p.seg[c].mask | (p.seg[c].first << 8) | (p.seg[c].last << 9) | (p.cls_oy[cl] << 10) | (p.cls_ox[cl] << 11);
+        e[3] = p.seg[c].wbase;
     }
     if (WLDS) {
         const int nchunk = p.nwfrag * 64;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
     // the address space must be static: a pointer that is "LDS or global" compiles to flat loads, whose waits drain both counters
     const h16x8* wglob = reinterpret_cast<const h16x8*>(a.wpk) + lane;
     const unsigned char* wlds_lane = wl + 16 * lane;
-    const int ncls = p.ncls, up = p.up, pixstride = p.pixstride;
+    const int nseg = p.nseg, up = p.up, pixstride = p.pixstride;
     unsigned base[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) base[r] = (unsigned)(((RPW * wv + r) * p.stride * p.PW + nl * p.stride) * p.pixstride);
@@ -330,13 +340,15 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
 
     PatchGeom<NPF> Gm;
     patch_geom<NPF, SRC>(a, p, tid, Gm);
+    // this lane's output elements relative to the tile's first output pixel (NHWC destination): row r of the wave, column nl
+    const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 2;  // bytes between this wave's consecutive rows
     PatchRegs<NPF, SRC> R;
     int it = 0, cur_n = -1;
     int t = persistent_tile(it, blockIdx.x, G);
-    if (t < total_tiles) patch_fetch<NPF, SRC>(a, p, t, TH, Gm, R);
+    if (t < total_tiles) patch_fetch<NPF, SRC>(a, p, t, TH, tid, Gm, R);
     while (t < total_tiles) {
-        const int n = t / ntile, tt = t - n * ntile;
-        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
         const int gy0 = ty * TH, gx0 = tx * F16_TW;
         if (want_stats && n != cur_n) {
             if (cur_n >= 0) flush_stats(cur_n);
@@ -345,90 +357,118 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
         if (!(a.dbg & 8)) patch_commit<NPF, SRC>(a, p, n, tid, Gm, R, patch);
         __syncthreads();
         const int tnext = persistent_tile(it + 1, blockIdx.x, G);
-        if (tnext < total_tiles && !(a.dbg & 4)) patch_fetch<NPF, SRC>(a, p, tnext, TH, Gm, R);
+        if (tnext < total_tiles && !(a.dbg & 4)) patch_fetch<NPF, SRC>(a, p, tnext, TH, tid, Gm, R);
 
-        for (int cls = 0; cls < ncls; ++cls) {
-            f32x4 acc[RPW][NF];
-            const int4 ci = *reinterpret_cast<const int4*>(smem + 16 * (F16_MAX_STEPS + cls));
+        f32x4 acc[RPW][NF];
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int4 ci = *reinterpret_cast<const int4*>(smem + 16 * (F16_MAX_STEPS + sg));
             const int s0 = __builtin_amdgcn_readfirstlane(ci.x), s1 = __builtin_amdgcn_readfirstlane(ci.y);
-            // K-steps as a three-stage pipeline over LDS (all reads return in order, so the waits are counted, never drains):
-            //   table entry of step s+2  |  operand fragments of step s+1 (address from the entry read one stage earlier)  |  MFMAs of s
-            struct StepMeta { unsigned ko, fm; int wi; };
-            auto load_meta = [&](int s) -> StepMeta {
-                StepMeta m;
-                m.ko = *reinterpret_cast<const uint16_t*>(smem + 16 * s + 2 * g);
-                if (NF > 2) {
-                    const unsigned meta = *reinterpret_cast<const unsigned*>(smem + 16 * s + 8);
-                    m.fm = meta & 0xffffu;
-                    m.wi = (int)(meta >> 16);
-                } else {
-                    m.fm = (1u << NF) - 1;
-                    m.wi = s * NF;  // every fragment of every step is stored
-                }
-                return m;
-            };
-            auto load_ops = [&](const StepMeta& m, h16x8 (&bf)[RPW], h16x8 (&af)[NF], unsigned& fm) {
-                fm = NF > 2 ? (unsigned)__builtin_amdgcn_readfirstlane((int)m.fm) : m.fm;
-                int wi = NF > 2 ? __builtin_amdgcn_readfirstlane(m.wi) : m.wi;
+            const int sflags = __builtin_amdgcn_readfirstlane(ci.z), wbase = __builtin_amdgcn_readfirstlane(ci.w);
+            const int smask = sflags & 0xff;
+            // a single output fragment never splits into segments: first / last are compile-time there (keeps the light kernels lean)
+            const bool first = NF == 1 ? true : (bool)((sflags >> 8) & 1), last = NF == 1 ? true : (bool)((sflags >> 9) & 1);
+            // One segment = K-steps that all feed the fragment set MASK (compile-time inside `run`): no per-step branches, no per-step
+            // metadata beyond the lane's patch offset.  Three-stage pipeline over LDS (reads return in order: counted waits only):
+            //   patch offset of step s+2 | operand fragments of step s+1 | MFMAs of step s
+            auto run = [&](auto MT) {
+                constexpr unsigned MASK = decltype(MT)::value;
+                constexpr int NLIVE = __builtin_popcount(MASK);
+                auto load_ko = [&](int s) -> unsigned { return *reinterpret_cast<const uint16_t*>(smem + 16 * s + 2 * g); };
+                auto load_ops = [&](unsigned ko, int s, h16x8 (&bf)[RPW], h16x8 (&af)[NF]) {
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    if (SRC == 1) {  // 8-byte pixels: the 16 bytes of a tap pair are only 8-byte aligned -> two 8-byte reads
-                        const h16x4 lo = *reinterpret_cast<const h16x4*>(patch + base[r] + m.ko);
-                        const h16x4 hi = *reinterpret_cast<const h16x4*>(patch + base[r] + m.ko + 8);
-                        bf[r] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    } else {
-                        bf[r] = *reinterpret_cast<const h16x8*>(patch + base[r] + m.ko);
+                    for (int r = 0; r < RPW; ++r) {
+                        if (SRC == 1) {  // 8-byte pixels: the 16 bytes of a tap pair are only 8-byte aligned -> two 8-byte reads
+                            const h16x4 lo = *reinterpret_cast<const h16x4*>(patch + base[r] + ko);
+                            const h16x4 hi = *reinterpret_cast<const h16x4*>(patch + base[r] + ko + 8);
+                            bf[r] = h16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        } else {
+                            bf[r] = *reinterpret_cast<const h16x8*>(patch + base[r] + ko);
+                        }
                     }
+                    int wi = wbase + (s - s0) * NLIVE;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        if ((MASK >> f) & 1) {
+                            if (WLDS) af[f] = *reinterpret_cast<const h16x8*>(wlds_lane + (size_t)wi * 1024);
+                            else af[f] = wglob[(size_t)wi * 64];
+                            ++wi;
+                        }
+                };
+                auto mma_step = [&](const h16x8 (&bf)[RPW], const h16x8 (&af)[NF], auto from_bias) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        if ((MASK >> f) & 1) {
+#pragma unroll
+                            for (int r = 0; r < RPW; ++r)
+                                acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bf[r], decltype(from_bias)::value ? b4[f] : acc[r][f], 0, 0, 0);
+                        }
+                };
+                auto clip = [&](int s) { return s < s1 ? s : s1 - 1; };  // past the end: re-read the last step (loaded, never used)
+                h16x8 bA[RPW], aA[NF], bB[RPW], aB[NF];
+                unsigned k0 = load_ko(s0), k1 = load_ko(clip(s0 + 1));
+                load_ops(k0, s0, bA, aA);
+                k0 = load_ko(clip(s0 + 2));
+                load_ops(k1, clip(s0 + 1), bB, aB);
+                if (first) mma_step(bA, aA, TrueT{});   // accumulators start from the bias (MFMA C operand)
+                else mma_step(bA, aA, FalseT{});
+                int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), k0 the offset of step s + 1
+                for (; s + 1 < s1; s += 2) {
+                    k1 = load_ko(clip(s + 2));
+                    load_ops(k0, s + 1, bA, aA);
+                    mma_step(bB, aB, FalseT{});
+                    k0 = load_ko(clip(s + 3));
+                    load_ops(k1, clip(s + 2), bB, aB);
+                    mma_step(bA, aA, FalseT{});
                 }
+                if (s < s1) mma_step(bB, aB, FalseT{});
+            };
+            if (first) {  // fragments the first segment does not feed start from the bias as well
 #pragma unroll
                 for (int f = 0; f < NF; ++f)
-                    if (NF <= 2 || ((fm >> f) & 1)) {
-                        if (WLDS) af[f] = *reinterpret_cast<const h16x8*>(wlds_lane + (size_t)wi * 1024);
-                        else af[f] = wglob[(size_t)wi * 64];
-                        ++wi;
-                    }
-            };
-            // first = true: the accumulators start from the bias (MFMA C operand), so no accumulator is ever initialised separately
-            auto mma_step = [&](const h16x8 (&bf)[RPW], const h16x8 (&af)[NF], unsigned fm, auto first) {
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    if (NF <= 2 || ((fm >> f) & 1)) {
-#pragma unroll
-                        for (int r = 0; r < RPW; ++r)
-                            acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[f], bf[r], decltype(first)::value ? b4[f] : acc[r][f], 0, 0, 0);
-                    } else if (decltype(first)::value) {
+                    if (!((smask >> f) & 1) || (a.dbg & 1)) {
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) acc[r][f] = b4[f];
                     }
+            }
+            if (!(a.dbg & 1)) {
+                if (NF == 1) run(MaskT<1>{});
+                else if (NF == 2) {
+                    if (smask == 3) run(MaskT<3>{});
+                    else if (smask == 1) run(MaskT<1>{});
+                    else run(MaskT<2>{});
+                } else {
+                    if (smask == 15) run(MaskT<15>{});
+                    else if (smask == 1) run(MaskT<1>{});
+                    else if (smask == 2) run(MaskT<2>{});
+                    else if (smask == 4) run(MaskT<4>{});
+                    else if (smask == 8) run(MaskT<8>{});
+                    else if (smask == 3) run(MaskT<3>{});
+                    else run(MaskT<12>{});
                 }
-            };
-            auto clip = [&](int s) { return s < s1 ? s : s1 - 1; };  // past the end: re-read the last step (loaded, never used)
-            if (a.dbg & 1) {
+            }
+            if (!last) continue;
+            // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) -------
+            const int oyc = up ? (sflags >> 10) & 1 : 0, oxc = up ? (sflags >> 11) & 1 : 0, mul = up ? 2 : 1;
+            if (DST == 0 && gy0 + TH <= a.Gh && gx0 + F16_TW <= a.Gw && (a.Cout & 15) == 0 && !(a.dbg & 2)) {
+                // whole tile inside the image (almost all of them): no per-lane bounds, addresses = tile base + a per-lane constant
+                char* ybase = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 2;
+                const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 2u;  // recomputed per tile: a register less
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[r][f] = b4[f];
-            } else {
-                h16x8 bA[RPW], aA[NF], bB[RPW], aB[NF];
-                unsigned fmA = 0, fmB = 0;
-                StepMeta m0 = load_meta(s0), m1 = load_meta(clip(s0 + 1));
-                load_ops(m0, bA, aA, fmA);
-                m0 = load_meta(clip(s0 + 2));
-                load_ops(m1, bB, aB, fmB);
-                mma_step(bA, aA, fmA, TrueT{});
-                int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), m0 the table entry of step s + 1
-                for (; s + 1 < s1; s += 2) {
-                    m1 = load_meta(clip(s + 2));
-                    load_ops(m0, bA, aA, fmA);
-                    mma_step(bB, aB, fmB, FalseT{});
-                    m0 = load_meta(clip(s + 3));
-                    load_ops(m1, bB, aB, fmB);
-                    mma_step(bA, aA, fmA, FalseT{});
-                }
-                if (s < s1) mma_step(bB, aB, fmB, FalseT{});
+                    for (int f = 0; f < NF; ++f) {
+                        const f32x4 v = acc[r][f];
+                        if (want_stats) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { ssum[f][q] += v[q]; ssq[f][q] += v[q] * v[q]; }
+                        }
+                        h16x4 hv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hv[q] = (h16)v[q];
+                        *reinterpret_cast<h16x4*>(ybase + r * out_row + out_off0 + 32 * f) = hv;
+                    }
+                continue;
             }
-            // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) -------
-            const int oyc = up ? __builtin_amdgcn_readfirstlane(ci.z) : 0, oxc = up ? __builtin_amdgcn_readfirstlane(ci.w) : 0, mul = up ? 2 : 1;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int gy = gy0 + RPW * wv + r, gx = gx0 + nl;
@@ -668,9 +708,13 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
                     pt.h[s][k][0] = pt.h[s][k][1] = PackHalf{PK_ZERO, 0, 0, 0, -1};
                 }
             }
-            // up to two output fragments: every step feeds both (zero filter rows where a tap has no business), which keeps the
-            // K-loop free of branches and of per-step metadata; four fragments (64-channel MultiScaleBlock): only the live ones
-            p.fmask[s] = p.NF <= 2 ? (uint8_t)((1u << p.NF) - 1) : (uint8_t)(fm & ((1u << p.NF) - 1));
+            {
+                // the kernel instantiates its K loop for these fragment sets; anything else is widened to all fragments (the packed
+                // filter then holds zero rows where a tap has no business)
+                const unsigned full = (1u << p.NF) - 1, m = fm & full;
+                const bool ok = m == full || m == 1 || m == 2 || m == 4 || m == 8 || (p.NF == 4 && (m == 3 || m == 12));
+                p.fmask[s] = (uint8_t)(ok ? m : full);
+            }
         }
     }
     p.cls_begin[p.ncls] = s;
@@ -688,6 +732,20 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
             }
     }
     p.nwfrag = nw;
+    // segments: maximal runs of steps of one class with one fragment mask (masks outside the kernel's instantiated set are widened)
+    p.nseg = 0;
+    for (int cls = 0; cls < p.ncls; ++cls) {
+        for (int st = p.cls_begin[cls]; st < p.cls_begin[cls + 1];) {
+            int e = st + 1;
+            while (e < p.cls_begin[cls + 1] && p.fmask[e] == p.fmask[st]) ++e;
+            if (p.nseg >= F16_MAX_SEG) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: too many fragment-mask segments");
+            F16Plan::Seg& sg = p.seg[p.nseg++];
+            sg.s0 = (int16_t)st; sg.s1 = (int16_t)e; sg.mask = p.fmask[st]; sg.cls = (uint8_t)cls;
+            sg.first = st == p.cls_begin[cls]; sg.last = e == p.cls_begin[cls + 1];
+            sg.wbase = p.wofs[st];
+            st = e;
+        }
+    }
     // tile height (16 or 8 rows) and where the filter lives: prefer two workgroups per CU with the filter in LDS (<= 78 KiB each),
     // then one workgroup with the filter in LDS, then the filter from global memory
     const int ext = halo_hi - halo_lo;
@@ -699,7 +757,13 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
     };
     const size_t wb = (size_t)nw * 1024 + F16_TABLE_BYTES;
     int TH;
-    if (wb + patch_bytes_of(16) <= 78 * 1024) { TH = 16; p.wlds = 1; }
+    int th_max = 16;  // measured (tools/f16_ab.sh): 32-row tiles lose 10-30 % on every NHWC layer and are a wash on the stem
+    { const char* e = getenv("MSTG_F16_TH"); if (e) th_max = atoi(e); }  // experiments: cap the tile height
+    // one output fragment: 32-row tiles (eight rows per wave) halve everything a tile does once per step / per tile and cut the
+    // halo share; taken when two workgroups per CU still fit and the image is tall enough to have whole tiles
+    const int gh_plan = d->kind == 1 ? d->H : d->Ho;
+    if (p.NF == 1 && th_max >= 32 && gh_plan >= 32 && wb + patch_bytes_of(32) <= 78 * 1024) { TH = 32; p.wlds = 1; }
+    else if (wb + patch_bytes_of(16) <= 78 * 1024) { TH = 16; p.wlds = 1; }
     else if (wb + patch_bytes_of(8) <= 78 * 1024) { TH = 8; p.wlds = 1; }
     else if (wb + patch_bytes_of(16) <= 156 * 1024) { TH = 16; p.wlds = 1; }
     else if (wb + patch_bytes_of(8) <= 156 * 1024) { TH = 8; p.wlds = 1; }
@@ -755,7 +819,9 @@ static int launch_conv(const F16ConvArgs& a, const F16Plan& p, int src, int dst,
 
 template <int RPW, int NF>
 static int launch_conv_npf(const F16ConvArgs& a, const F16Plan& p, int src, int dst, size_t lds, long grid, hipStream_t st, int* grid_out) {
+    if (p.npf <= 2) return launch_conv<RPW, NF, 2>(a, p, src, dst, lds, grid, st, grid_out);
     if (p.npf <= 4) return launch_conv<RPW, NF, 4>(a, p, src, dst, lds, grid, st, grid_out);
+    if (p.npf <= 6) return launch_conv<RPW, NF, 6>(a, p, src, dst, lds, grid, st, grid_out);
     if (p.npf <= 8) return launch_conv<RPW, NF, 8>(a, p, src, dst, lds, grid, st, grid_out);
     return launch_conv<RPW, NF, 12>(a, p, src, dst, lds, grid, st, grid_out);
 }
@@ -825,6 +891,11 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     { const char* e = getenv("MSTG_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
     if (tiles > 0x7fffffffL) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: too many tiles");
+    // the kernel divides tile indices by multiply-high: exact while index * divisor < 2^32
+    if ((unsigned long long)(tiles + 4096) * (unsigned long long)(a.tiles_x * a.tiles_y) >= (1ull << 32))
+        return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: batch x tiles too large for the tile-index arithmetic");
+    p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
+    p.m_tx = magic_u32((unsigned)a.tiles_x);
     a.partial = nullptr;
     if (out_stats) {
         const size_t need = (size_t)a.N * F16_MAX_GRID * 2 * 16 * p.NF * sizeof(float);
@@ -841,7 +912,9 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     hipStream_t st = (hipStream_t)stream;
     const int src = d->src_nchw_f32 ? 1 : 0, dst = d->dst_nchw ? 1 : 0;
     int lrc;
-    if (p.TH == 16) {
+    if (p.TH == 32) {
+        lrc = launch_conv_npf<8, 1>(a, p, src, dst, lds, grid, st, &launched);
+    } else if (p.TH == 16) {
         switch (p.NF) {
             case 1: lrc = launch_conv_npf<4, 1>(a, p, src, dst, lds, grid, st, &launched); break;
             case 2: lrc = launch_conv_npf<4, 2>(a, p, src, dst, lds, grid, st, &launched); break;
@@ -948,12 +1021,12 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const h16* __restrict__ x
     // ---- normalise-on-load constants: this lane always stages the same channel octet ------------------------------------------
     constexpr int OCT = C / 8;
     const int o = l % OCT;
-    float mu[8], rs[8];
+    float sc[8], nb[8];  // (x - mean) * rstd = x * sc + nb
     const bool norm = in_stats != nullptr;
     if (norm) {
         const float* st = in_stats + ((size_t)n * C + 8 * o) * 2;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { mu[c] = st[2 * c]; rs[c] = st[2 * c + 1]; }
+        for (int c = 0; c < 8; ++c) { sc[c] = st[2 * c + 1]; nb[c] = -st[2 * c] * st[2 * c + 1]; }
     }
     h16* Xs = tile + T::X;
     h16* QTs = tile + T::QT;
@@ -973,10 +1046,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const h16* __restrict__ x
             h16x8 v = *reinterpret_cast<const h16x8*>(x + img + ((size_t)yy * W + xx) * C + 8 * o);
             if (norm) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float f = ((float)v[c] - mu[c]) * rs[c];
-                    v[c] = (h16)(f > 0.f ? f : 0.f);
-                }
+                for (int c = 0; c < 8; ++c) v[c] = (h16)fmaxf(fmaf((float)v[c], sc[c], nb[c]), 0.f);
             }
             *reinterpret_cast<h16x8*>(&Xs[p * T::LDX + 8 * o]) = v;
         }
@@ -999,7 +1069,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const h16* __restrict__ x
             }
             f32x4 inv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) inv[r] = 1.f / fmaxf(sqrtf(row16_sum_f(ss[r])), 1e-12f);
+            for (int r = 0; r < 4; ++r) inv[r] = fminf(__builtin_amdgcn_rsqf(row16_sum_f(ss[r])), 1e12f);  // 1 / max(||.||, 1e-12)
             h16* dst = part == 0 ? QTs : KTs;
 #pragma unroll
             for (int nf = 0; nf < NB; ++nf) {
@@ -1037,7 +1107,7 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const h16* __restrict__ x
             }
             sum += __shfl_xor(sum, 16, 64);
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
             for (int mf = 0; mf < NB; ++mf) {
                 h16x4v hv;
