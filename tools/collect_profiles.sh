@@ -10,7 +10,7 @@ for v in prof prof1; do
   [ -n "$f" ] || continue
   name=$([ $v = prof ] && echo "" || echo "_one_stream")
   cp $f $dst/${tag}_bench_b32_256${name}_kernel_stats.csv
-  python tools/profile_summary.py $f 7 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline  ($([ $v = prof ] && echo 'two streams (default)' || echo 'MSTG_STREAMS=0'); 5 timed + 2 warm-up steps, per-step figures = totals / 7 incl. the instrumented step)" > $dst/${tag}_bench_b32_256${name}_summary.txt
+  python tools/profile_summary.py $f 8 "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline  ($([ $v = prof ] && echo 'two streams (default)' || echo 'MSTG_STREAMS=0'); 2 warm-up + 5 timed + 1 instrumented step: per-step figures = totals / 8)" > $dst/${tag}_bench_b32_256${name}_summary.txt
 done
 [ -f $src/${tag}_pmc_traffic.json ] && cp $src/${tag}_pmc_traffic.json $dst/
 [ -f $src/${tag}_c16_sq.txt ] && cp $src/${tag}_c16_sq.txt $dst/${tag}_sq_counters_c16.txt
