@@ -38,7 +38,14 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+def _flags() -> str:
+    return " ".join(os.environ.get("MSTG_HIPCC_FLAGS", "").split())
+
+
 def needs_build() -> bool:
+    flags_file = os.path.join(OBJ, "flags.txt")
+    if os.path.exists(flags_file) and open(flags_file).read() != _flags():
+        return True  # built with other MSTG_HIPCC_FLAGS
     return _stale(LIB, sources() + headers())
 
 
