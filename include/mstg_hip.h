@@ -92,6 +92,12 @@ int mstg_norm_act_fwd(const float* x, const float* residual /*nullable*/, float*
 int mstg_norm_act_bwd(const float* x, const float* stats, const float* dy, float* dx, int N, int HW, int C, int act,
                       int batch_stats, const float* gamma, const float* beta, float* dgamma, float* dbeta,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The two halves on their own, for a norm whose neighbours do the other half (mstg_window_attn_norm_*): statistics only
+ * (stats[n][c] = {mean, rstd}, bit-identical to what mstg_norm_act_fwd stores), and the backward's apply pass given
+ * sums[n][s][2][C]: rows that add up, per (image, channel), to sum(dy * act') and sum(dy * act' * x^) (InstanceNorm only). */
+int mstg_norm_stats(const float* x, float* stats, int N, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
+int mstg_norm_bwd_apply(const float* x, const float* stats, const float* dy, const float* sums /* [N][sums_split][2][C] */,
+                        int sums_split, float* dx, int N, int HW, int C, int act, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LocalAttention core (enhanced_generator.py:22-35,39-42), window 4x4.  The qkv and proj 1x1 convolutions
@@ -113,6 +119,18 @@ int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, i
 int mstg_window_attn_fused_supported(int C);
 int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
                          float* y, int N, int H, int W, int C, void* stream);
+/* The stage's first InstanceNorm + ReLU (enhanced_generator.py:93-94, 100-101, 122-123, 129-130) folded into LocalAttention, its
+ * only consumer: x_raw is the convolution output in front of the norm, in_stats[n][c] = (mean, rstd) from mstg_norm_stats; the
+ * normalised tensor never exists in memory.  The backward also returns norm_sums[n][S][2][C], S = mstg_window_attn_norm_sums_split():
+ * rows adding up to the per (image, channel) sums of dz * [z > 0] and dz * [z > 0] * z for mstg_norm_bwd_apply (the norm backward's
+ * reduction pass, done in this kernel's epilogue). */
+int mstg_window_attn_norm_sums_split(void);
+int mstg_window_attn_norm_fwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv, const float* wproj,
+                              const float* bproj, float* y, int N, int H, int W, int C, void* stream);
+size_t mstg_window_attn_norm_bwd_workspace_bytes(int N, int H, int W, int C);
+int mstg_window_attn_norm_bwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv, const float* wproj,
+                              const float* bproj, const float* dy, float* dz, float* dparams, float* norm_sums, int N, int H, int W,
+                              int C, void* workspace, size_t workspace_bytes, void* stream);
 size_t mstg_window_attn_bwd_workspace_bytes(int N, int H, int W, int C);
 int mstg_window_attn_bwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
                          const float* dy, float* dx, float* dparams, int N, int H, int W, int C, void* workspace,

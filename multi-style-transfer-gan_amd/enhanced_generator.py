@@ -88,8 +88,14 @@ class _Stage(nn.Sequential):
 
     def forward_nhwc(self, x):
         x = self[0](x, nhwc=True)
-        x = ops.instnorm_act(x, ACT_RELU)
-        x = self[3].forward_nhwc(x)
+        att = self[3]
+        if (att.window_size == 4 and ops.fused_attention_supported(x.shape[3]) and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0
+                and os.environ.get("MSTG_ATTN_UNFUSED") != "1" and os.environ.get("MSTG_NORM_ATTN", "1") != "0"):
+            # IN + ReLU folded into the attention kernels (its only consumer): the normalised tensor is never written
+            x = ops.NormLocalAttentionFn.apply(x, att.qkv.weight, att.qkv.bias, att.proj.weight, att.proj.bias)
+        else:
+            x = ops.instnorm_act(x, ACT_RELU)
+            x = att.forward_nhwc(x)
         return self[4].forward_nhwc(x)
 
     def forward(self, x):

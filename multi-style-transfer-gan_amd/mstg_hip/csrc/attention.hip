@@ -138,6 +138,30 @@ __device__ __forceinline__ void put_window(const f32x4 (&r)[C / 16], float* tile
     }
 }
 
+// InstanceNorm + ReLU folded into the window load (the stage's first norm, whose only consumer is this module): the lane's
+// channel quad is the same for every element it stages, so it needs (mean, rstd) of 4 channels of the window's image.
+struct QuadStats { f32x4 a, b; };  // a = (mean0, rstd0, mean1, rstd1), b = (mean2, rstd2, mean3, rstd3): stats[n][c][2] as stored
+template <int C>
+__device__ __forceinline__ void fetch_stats(QuadStats& qs, const float* __restrict__ stats, int n, int lane) {
+    const float* st = stats + ((size_t)n * C + 4 * (lane % (C / 4))) * 2;
+    qs.a = *reinterpret_cast<const f32x4*>(st);
+    qs.b = *reinterpret_cast<const f32x4*>(st + 4);
+}
+template <int C>
+__device__ __forceinline__ void put_window_norm(const f32x4 (&r)[C / 16], const QuadStats& qs, float* tile, int ld, int lane) {
+    constexpr int qpb = C / 4;
+#pragma unroll
+    for (int k = 0; k < C / 16; ++k) {
+        const int e = lane + 64 * k, q = e % qpb, p = e / qpb;
+        f32x4 v = r[k];  // same arithmetic as norm_apply_kernel: (x - mean) * rstd, then ReLU
+        v[0] = fmaxf((v[0] - qs.a[0]) * qs.a[1], 0.f);
+        v[1] = fmaxf((v[1] - qs.a[2]) * qs.a[3], 0.f);
+        v[2] = fmaxf((v[2] - qs.b[0]) * qs.b[1], 0.f);
+        v[3] = fmaxf((v[3] - qs.b[2]) * qs.b[3], 0.f);
+        *reinterpret_cast<f32x4*>(&tile[p * ld + 4 * q]) = v;
+    }
+}
+
 // q^ , k^ , P into LDS; returns with tiles ready
 template <int CP>
 __device__ __forceinline__ void attn_forward_tiles(float* sm, int C, int lane) {
@@ -387,27 +411,32 @@ __device__ __forceinline__ void fused_forward_tiles(float* sm, const float* __re
     ATT_FSTAMP(5)
 }
 
-template <int C>
+template <int C, bool NORM>
 __global__ __launch_bounds__(64) void attn_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wqkv,
                                                             const float* __restrict__ bqkv, const float* __restrict__ wp,
-                                                            const float* __restrict__ bp, float* __restrict__ y, int N, int H, int W) {
+                                                            const float* __restrict__ bp, float* __restrict__ y, int N, int H, int W,
+                                                            const float* __restrict__ in_stats) {
     typedef FusedTiles<C> F;
     constexpr int NF = F::NF;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
     const int nwx = W / 4, nwy = H / 4, nwin = N * nwy * nwx;
     f32x4 xr[C / 16];
+    QuadStats qs;
     if ((int)blockIdx.x < nwin) {
         const int w = blockIdx.x;
         fetch_window<C>(xr, x, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
+        if (NORM) fetch_stats<C>(qs, in_stats, w / (nwx * nwy), lane);
     }
     for (int w = blockIdx.x; w < nwin; w += gridDim.x) {
         const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
         WAVE_SYNC();
-        put_window<C>(xr, sm + F::XS, F::LDX, lane);
+        if (NORM) put_window_norm<C>(xr, qs, sm + F::XS, F::LDX, lane);
+        else put_window<C>(xr, sm + F::XS, F::LDX, lane);
         {
             const int w2 = w + gridDim.x < nwin ? w + gridDim.x : w;  // next window of this wave (re-fetch the same one at the end)
             fetch_window<C>(xr, x, H, W, w2 / (nwx * nwy), (w2 / nwx) % nwy, w2 % nwx, lane);
+            if (NORM) fetch_stats<C>(qs, in_stats, w2 / (nwx * nwy), lane);
         }
         fused_forward_tiles<C>(sm, nullptr, wqkv, bqkv, H, W, n, wy, wx, lane);
         // Y^T[co][p] = sum_c Wp[co][c] O[p][c] + b : rows = channels -> one 16-byte store per lane and fragment
@@ -424,11 +453,16 @@ __global__ __launch_bounds__(64) void attn_fused_fwd_kernel(const float* __restr
     }
 }
 
-template <int C>
+// NORM: x is the RAW tensor in front of the stage's InstanceNorm + ReLU (normalised while staged), and the kernel also emits what
+// that norm's backward needs from a pass over dx: per (image, channel) the sums of dx * [z > 0] and dx * [z > 0] * z.  A wave takes
+// its windows in runs of kblk consecutive ones (kblk divides the windows per image, so a run stays inside one image) and writes
+// one row per run: nsum[run][2][C], runs of an image being consecutive.  kblk = 1 without NORM: the plain strided order.
+template <int C, bool NORM>
 __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ wqkv,
                                                             const float* __restrict__ bqkv, const float* __restrict__ wp,
                                                             const float* __restrict__ bp, const float* __restrict__ dy,
-                                                            float* __restrict__ dx, float* __restrict__ partial, int N, int H, int W) {
+                                                            float* __restrict__ dx, float* __restrict__ partial, int N, int H, int W,
+                                                            const float* __restrict__ in_stats, float* __restrict__ nsum, int kblk) {
     typedef FusedTiles<C> F;
     typedef AttnTiles<C> T;
     constexpr int NF = F::NF;
@@ -456,23 +490,50 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
     for (int nf = 0; nf < NF; ++nf) gbp[nf] = 0.f;
 
     f32x4 xr[C / 16], dyr[C / 16];
-    if ((int)blockIdx.x < nwin) {
-        const int w = blockIdx.x;
+    QuadStats qs;
+    f32x4 ns1[NORM ? NF : 1], ns2[NORM ? NF : 1];  // this wave's norm-backward sums over the current run of windows
+    if (NORM) {
+#pragma unroll
+        for (int mf = 0; mf < NF; ++mf) ns1[mf] = ns2[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto flush_nsum = [&](int run) {
+        float* row = nsum + (size_t)run * 2 * C;
+#pragma unroll
+        for (int mf = 0; mf < (NORM ? NF : 1); ++mf) {
+            f32x4 a, b;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = row16_sum(ns1[mf][r]); b[r] = row16_sum(ns2[mf][r]); }
+            if (i == 0) {
+                *reinterpret_cast<f32x4*>(row + 16 * mf + 4 * g) = a;
+                *reinterpret_cast<f32x4*>(row + C + 16 * mf + 4 * g) = b;
+            }
+            ns1[mf] = ns2[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    const int nrun = nwin / kblk;  // kblk divides nwin
+    if ((int)blockIdx.x < nrun) {
+        const int w = blockIdx.x * kblk;
         fetch_window<C>(dyr, dy, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
         fetch_window<C>(xr, x, H, W, w / (nwx * nwy), (w / nwx) % nwy, w % nwx, lane);
+        if (NORM) fetch_stats<C>(qs, in_stats, w / (nwx * nwy), lane);
     }
     int wcount = 0;
-    for (int w = blockIdx.x; w < nwin; w += gridDim.x, ++wcount) {
+    for (int run = blockIdx.x, j = 0; run < nrun; ++wcount) {
+        const int w = run * kblk + j;
         const int wx = w % nwx, wy = (w / nwx) % nwy, n = w / (nwx * nwy);
+        // the window after this one: the run's next, or the first of this wave's next run (at the very end: this one again)
+        const bool run_ends = j + 1 == kblk;
+        const int w2 = !run_ends ? w + 1 : (run + (int)gridDim.x < nrun ? (run + (int)gridDim.x) * kblk : w);
         WAVE_SYNC();
         ATT_STAMP(0)
         put_window<C>(dyr, dYs, F::LDX, lane);
-        put_window<C>(xr, sm + F::XS, F::LDX, lane);
-        {
-            const int w2 = w + gridDim.x < nwin ? w + gridDim.x : w;  // next window of this wave: in flight behind this one's compute
+        if (NORM) put_window_norm<C>(xr, qs, sm + F::XS, F::LDX, lane);
+        else put_window<C>(xr, sm + F::XS, F::LDX, lane);
+        {   // in flight behind this window's compute
             const int n2 = w2 / (nwx * nwy), wy2 = (w2 / nwx) % nwy, wx2 = w2 % nwx;
             fetch_window<C>(dyr, dy, H, W, n2, wy2, wx2, lane);
             fetch_window<C>(xr, x, H, W, n2, wy2, wx2, lane);
+            if (NORM) fetch_stats<C>(qs, in_stats, n2, lane);
         }
         fused_forward_tiles<C>(sm, nullptr, wqkv, bqkv, H, W, n, wy, wx, lane);  // Xs (filled above), q^, k^, v, P, inverse norms, Os
         ATT_STAMP(1)
@@ -552,6 +613,18 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
             float* dst = dx + (((size_t)n * H + py) * W + px) * C;
 #pragma unroll
             for (int mf = 0; mf < NF; ++mf) *reinterpret_cast<f32x4*>(dst + 16 * mf + 4 * g) = d[mf][0];
+            if (NORM) {  // Xs holds z = relu(x^): where z > 0 it IS x^, elsewhere the element contributes nothing
+#pragma unroll
+                for (int mf = 0; mf < NF; ++mf) {
+                    const f32x4 z = *reinterpret_cast<const f32x4*>(&sm[F::XS + i * F::LDX + 16 * mf + 4 * g]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gg = z[r] > 0.f ? d[mf][0][r] : 0.f;
+                        ns1[mf][r] += gg;
+                        ns2[mf][r] += gg * z[r];
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -563,6 +636,13 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
         }
         ATT_STAMP(5)
         ATT_STAMP(6)
+        if (run_ends) {
+            if (NORM) flush_nsum(run);
+            run += gridDim.x;
+            j = 0;
+        } else {
+            ++j;
+        }
     }
     // ---- this wave's slab: dWqkv (3C x C) | dWp (C x C) | dbqkv (3C) | dbp (C) ---------------------------------------------
     float* out = partial + (size_t)blockIdx.x * F::SLAB;
@@ -604,25 +684,69 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     }
 }
 
+// sums[n][sp][2][C] = sum of the image's rows sp * R / S ... of nsum[n][R][2][C] (R rows per image, S splits), fixed order
+__global__ __launch_bounds__(256) void nsum_reduce_kernel(const float* __restrict__ nsum, float* __restrict__ sums, int R, int S, int C2) {
+    __shared__ f32x4 sh[256];
+    const int n = blockIdx.y, sp = blockIdx.x, tid = threadIdx.x;
+    const int Q = C2 / 4, q = tid % Q, rg = tid / Q, nrg = 256 / Q;
+    const int per = (R + S - 1) / S, r0 = sp * per, r1 = min(R, r0 + per);
+    const f32x4* src = reinterpret_cast<const f32x4*>(nsum) + (size_t)n * R * Q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rg; r < r1; r += nrg) acc += src[(size_t)r * Q + q];
+    sh[tid] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nrg; ++k) t += sh[k * Q + q];
+        reinterpret_cast<f32x4*>(sums)[((size_t)n * S + sp) * Q + q] = t;
+    }
+}
+
+// windows per run of the NORM backward: the largest divisor of the windows per image that is <= 16
+static int norm_run_len(int H, int W) {
+    const int wpi = (H / 4) * (W / 4);
+    for (int k = 16; k > 1; --k)
+        if (wpi % k == 0) return k;
+    return 1;
+}
+constexpr int NSUM_SPLIT = 16;  // rows of norm sums per image handed to mstg_norm_bwd_apply
+
 static int fused_blocks(int N, int H, int W) {
     const int nwin = N * (H / 4) * (W / 4);
     return nwin < 2048 ? nwin : 2048;  // one-wave workgroups: 8 per CU
 }
 
+// in_stats != nullptr: x is the raw tensor in front of InstanceNorm + ReLU; backward then also fills norm_sums[N][2][C]
+// (workspace layout: [weight-gradient slabs: nb * SLAB][nsum rows: N * nb * 2C])
 template <int C>
 static int launch_fused(bool bwd, const float* x, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
-                        const float* dy, float* out, float* grads, float* partial, int N, int H, int W, hipStream_t st) {
+                        const float* dy, float* out, float* grads, float* partial, int N, int H, int W, hipStream_t st,
+                        const float* in_stats = nullptr, float* norm_sums = nullptr) {
     typedef FusedTiles<C> F;
     const int nb = fused_blocks(N, H, W);
     if (!bwd) {
-        hipLaunchKernelGGL((attn_fused_fwd_kernel<C>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, out,
-                           N, H, W);
+        if (in_stats)
+            hipLaunchKernelGGL((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+                               out, N, H, W, in_stats);
+        else
+            hipLaunchKernelGGL((attn_fused_fwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+                               out, N, H, W, in_stats);
         MSTG_CHECK_LAUNCH("attn_fused_fwd_kernel");
         return MSTG_OK;
     }
-    hipLaunchKernelGGL((attn_fused_bwd_kernel<C>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy, out,
-                       partial, N, H, W);
-    MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
+    if (in_stats) {
+        float* nsum = partial + (size_t)nb * F::SLAB;
+        const int kblk = norm_run_len(H, W), R = (H / 4) * (W / 4) / kblk;
+        hipLaunchKernelGGL((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+                           out, partial, N, H, W, in_stats, nsum, kblk);
+        MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel<norm>");
+        hipLaunchKernelGGL(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
+        MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
+    } else {
+        hipLaunchKernelGGL((attn_fused_bwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+                           out, partial, N, H, W, in_stats, (float*)nullptr, 1);
+        MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
+    }
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB);
     MSTG_CHECK_LAUNCH("slab_reduce_kernel");
     return MSTG_OK;
@@ -1200,6 +1324,38 @@ extern "C" int mstg_window_attn_fwd(const float* x, const float* wqkv, const flo
     if (C == 16) return launch_fused<16>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
     if (C == 32) return launch_fused<32>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
     return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_fwd: fused kernel exists for C = 16 and 32 (use the qkv/core/proj chain otherwise)");
+}
+
+extern "C" int mstg_window_attn_norm_fwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv,
+                                         const float* wproj, const float* bproj, float* y, int N, int H, int W, int C, void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!x_raw || !in_stats || !wqkv || !bqkv || !wproj || !bproj || !y) return fail_arg(MSTG_E_BADARG, "window_attn_norm_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return launch_fused<16>(false, x_raw, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st, in_stats);
+    if (C == 32) return launch_fused<32>(false, x_raw, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st, in_stats);
+    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_fwd: fused kernel exists for C = 16 and 32");
+}
+
+extern "C" int mstg_window_attn_norm_sums_split(void) { return NSUM_SPLIT; }
+
+extern "C" size_t mstg_window_attn_norm_bwd_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32)) return 0;
+    const size_t nb = (size_t)fused_blocks(N, H, W);
+    return (nb * (4 * C * C + 4 * C) + (size_t)N * ((H / 4) * (W / 4) / norm_run_len(H, W)) * 2 * C) * sizeof(float);
+}
+
+extern "C" int mstg_window_attn_norm_bwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv,
+                                         const float* wproj, const float* bproj, const float* dy, float* dz, float* dparams,
+                                         float* norm_sums, int N, int H, int W, int C, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    if (int rc = attn_check(N, H, W, C)) return rc;
+    if (!x_raw || !in_stats || !wqkv || !bqkv || !wproj || !bproj || !dy || !dz || !dparams || !norm_sums || !workspace)
+        return fail_arg(MSTG_E_BADARG, "window_attn_norm_bwd: null pointer");
+    if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_bwd: fused kernel exists for C = 16 and 32");
+    if (workspace_bytes < mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_norm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 16) return launch_fused<16>(true, x_raw, wqkv, bqkv, wproj, bproj, dy, dz, dparams, (float*)workspace, N, H, W, st, in_stats, norm_sums);
+    return launch_fused<32>(true, x_raw, wqkv, bqkv, wproj, bproj, dy, dz, dparams, (float*)workspace, N, H, W, st, in_stats, norm_sums);
 }
 
 extern "C" size_t mstg_window_attn_bwd_workspace_bytes(int N, int H, int W, int C) {

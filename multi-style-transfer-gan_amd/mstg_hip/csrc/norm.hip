@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                                                          const float* __restrict__ beta, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float* __restrict__ dgamma,
                                                          float* __restrict__ dbeta, const float* __restrict__ partial,
-                                                         NormGeom g, int act, int batch) {
+                                                         NormGeom g, int act, int batch, int psplit) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][C]: a, b (+ mu, rs for backward)
     const int C = g.C, C4 = C >> 2, rows = 256 / C4;
     const int sp = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
@@ -124,9 +124,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         if (batch != 2) {
             const int nb = batch ? 0 : n, ne = batch ? g.N : n + 1;
             for (int nn = nb; nn < ne; ++nn)
-                for (int s = 0; s < g.split; ++s) {
-                    t1 += partial[((size_t)nn * g.split + s) * 2 * C + c];
-                    t2 += partial[((size_t)nn * g.split + s) * 2 * C + C + c];
+                for (int s = 0; s < psplit; ++s) {  // psplit = g.split, or 1 when a producer's epilogue already summed the tensor
+                    t1 += partial[((size_t)nn * psplit + s) * 2 * C + c];
+                    t2 += partial[((size_t)nn * psplit + s) * 2 * C + C + c];
                 }
         }
         if (!BWD) {
@@ -237,6 +237,26 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     }
 }
 
+// (mean, rstd) per (image, channel) from the pivoted partial sums: the arithmetic of norm_apply_kernel<false>, bit for bit
+__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, const float* __restrict__ partial,
+                                                         float* __restrict__ stats, NormGeom g) {
+    const int n = blockIdx.x, C = g.C;
+    const float cnt = (float)g.HW;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int s = 0; s < g.split; ++s) {
+            t1 += partial[((size_t)n * g.split + s) * 2 * C + c];
+            t2 += partial[((size_t)n * g.split + s) * 2 * C + C + c];
+        }
+        const float K = x[(size_t)n * g.HW * C + c];
+        const float e1 = t1 / cnt;
+        float var = t2 / cnt - e1 * e1;
+        var = var > 0.f ? var : 0.f;
+        stats[((size_t)n * C + c) * 2] = K + e1;
+        stats[((size_t)n * C + c) * 2 + 1] = rsqrtf(var + NORM_EPS);
+    }
+}
+
 static int norm_check(int N, int HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "norm: empty tensor");
     if (C % 4 || C > 1024) return fail_arg(MSTG_E_ALIGN, "norm: C must be a multiple of 4 and <= 1024");
@@ -271,7 +291,7 @@ extern "C" int mstg_norm_act_fwd(const float* x, const float* residual, float* y
         MSTG_CHECK_LAUNCH("norm_partial_kernel");
     }
     hipLaunchKernelGGL((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats,
-                       gamma, beta, running_mean, running_var, nullptr, nullptr, (const float*)workspace, g, act, batch_stats);
+                       gamma, beta, running_mean, running_var, nullptr, nullptr, (const float*)workspace, g, act, batch_stats, g.split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel");
     return MSTG_OK;
 }
@@ -293,7 +313,39 @@ extern "C" int mstg_norm_act_bwd(const float* x, const float* stats, const float
     MSTG_CHECK_LAUNCH("norm_partial_kernel<bwd>");
     hipLaunchKernelGGL((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx,
                        const_cast<float*>(stats), gamma, beta, nullptr, nullptr, dgamma, dbeta, (const float*)workspace, g, act,
-                       batch_stats);
+                       batch_stats, g.split);
+    MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
+    return MSTG_OK;
+}
+
+// InstanceNorm statistics only: stats[n][c] = (mean, rstd).  For a norm whose consumer normalises while it loads
+// (mstg_window_attn_norm_fwd): the normalised tensor is never written.
+extern "C" int mstg_norm_stats(const float* x, float* stats, int N, int HW, int C, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    if (int rc = norm_check(N, HW, C)) return rc;
+    if (!x || !stats || !workspace) return fail_arg(MSTG_E_BADARG, "norm_stats: null pointer");
+    const NormGeom g = norm_geom(N, HW, C);
+    if (workspace_bytes < mstg_norm_workspace_bytes(N, HW, C)) return fail_arg(MSTG_E_WORKSPACE, "norm_stats: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = 256 / (C / 4);
+    hipLaunchKernelGGL((norm_partial_kernel<false>), dim3(g.split, N), dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr,
+                       nullptr, nullptr, nullptr, (float*)workspace, g, MSTG_ACT_NONE, 0);
+    MSTG_CHECK_LAUNCH("norm_partial_kernel");
+    hipLaunchKernelGGL(norm_stats_kernel, dim3(N), dim3(256), 0, st, x, (const float*)workspace, stats, g);
+    MSTG_CHECK_LAUNCH("norm_stats_kernel");
+    return MSTG_OK;
+}
+
+// Second half of the InstanceNorm backward when the producer of dy already summed it: sums[n][2][C] = per (image, channel)
+// sum(dy * act'(.)) and sum(dy * act'(.) * x^) (mstg_window_attn_norm_bwd) -> dx = rstd * (dy * act' - mean1 - x^ * mean2).
+extern "C" int mstg_norm_bwd_apply(const float* x, const float* stats, const float* dy, const float* sums, int sums_split, float* dx,
+                                   int N, int HW, int C, int act, void* stream) {
+    if (int rc = norm_check(N, HW, C)) return rc;
+    if (!x || !stats || !dy || !sums || !dx) return fail_arg(MSTG_E_BADARG, "norm_bwd_apply: null pointer");
+    if (sums_split < 1) return fail_arg(MSTG_E_BADARG, "norm_bwd_apply: sums_split must be >= 1");
+    const NormGeom g = norm_geom(N, HW, C);
+    hipLaunchKernelGGL((norm_apply_kernel<true>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, dy,
+                       nullptr, dx, const_cast<float*>(stats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums, g, act, 0, sums_split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
     return MSTG_OK;
 }

@@ -480,6 +480,54 @@ class LocalAttentionFusedFn(torch.autograd.Function):
                 flat[4 * c2 + 3 * Cn:])
 
 
+class NormLocalAttentionFn(torch.autograd.Function):
+    """LocalAttention(ReLU(InstanceNorm2d(x))) with the norm folded into the attention kernels (C = 16 / 32): statistics pass over
+    x, then the attention forward normalises while it stages each window; the backward's attention kernel sums what the norm's
+    backward needs in its epilogue, so the norm costs one read in the forward and one read-read-write pass in the backward
+    instead of 3 + 5 tensor passes -- and the normalised tensor is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, wproj, bproj):
+        lib = _lib.load()
+        x = _req(x, "norm input")
+        wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
+        N, H, W, Cn = x.shape
+        stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+        _timed("norm_act_fwd", 0, 4 * x.numel(), lambda: _lib.check(
+            lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
+        y = torch.empty_like(x)
+        _timed(f"attn_fused_fwd_kernel<{Cn}>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+            lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
+            "mstg_window_attn_norm_fwd"))
+        ctx.save_for_backward(x, stats, wqkv, bqkv, wproj, bproj)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, stats, wqkv, bqkv, wproj, bproj = ctx.saved_tensors
+        dy = _req(dy, "attention grad_output")
+        N, H, W, Cn = x.shape
+        dz = torch.empty_like(x)
+        flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
+        S = lib.mstg_window_attn_norm_sums_split()
+        sums = torch.empty((N, S, 2, Cn), dtype=torch.float32, device=x.device)
+        ws = _ws(lib.mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, Cn), x.device)
+        _timed(f"attn_fused_bwd_kernel<{Cn}>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+            lib.mstg_window_attn_norm_bwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz), _p(flat),
+                                          _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_norm_bwd"))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _timed("norm_act_bwd", 0, 4 * x.numel() * 3, lambda: _lib.check(
+                lib.mstg_norm_bwd_apply(_p(x), _p(stats), _p(dz), _p(sums), S, _p(dx), N, H * W, Cn, ACT_RELU, _stream()),
+                "mstg_norm_bwd_apply"))
+        c2 = Cn * Cn
+        return (dx, flat[:3 * c2].view(3 * Cn, Cn, 1, 1), flat[4 * c2:4 * c2 + 3 * Cn], flat[3 * c2:4 * c2].view(Cn, Cn, 1, 1),
+                flat[4 * c2 + 3 * Cn:])
+
+
 def fused_attention_supported(Cn: int) -> bool:
     return bool(_lib.load().mstg_window_attn_fused_supported(int(Cn)))
 

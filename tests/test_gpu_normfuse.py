@@ -1,0 +1,84 @@
+"""InstanceNorm folded into its neighbours on the fp32 training path: the fused variants against
+the unfused chain of the same HIP kernels (which the module / golden-vector tests pin to the reference) and against torch fp32.
+Reference sites: conv -> InstanceNorm2d -> ReLU -> LocalAttention of every stage (enhanced_generator.py:93-95, 100-102,
+122-124, 129-131)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mstg_hip import _lib
+    _lib.load()
+
+
+def report(name, err, tol):
+    print(f"  [parity] {name:64s} rel-L2 {err:.2e} (tol {tol:.0e})")
+    assert err <= tol, f"{name}: {err:.3e} > {tol:.0e}"
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("Cn,N,H,W", [(16, 3, 16, 24), (32, 2, 24, 16), (16, 5, 64, 64), (32, 1, 8, 8)])
+def test_norm_attention_fused_vs_chain_and_torch(Cn, N, H, W):
+    """IN + ReLU folded into the fused attention kernels: forward bit-identical to norm kernel + attention kernel (same arithmetic,
+    same statistics), backward within fp32 summation-order noise of it; both against the oracle (torch fp32, CPU)."""
+    from mstg_hip import ops
+    x = rnd((N, H, W, Cn), 1, 2.0) + 0.5
+    wqkv, bqkv = rnd((3 * Cn, Cn, 1, 1), 2, Cn ** -0.5), rnd((3 * Cn,), 3, 0.1)
+    wp, bp = rnd((Cn, Cn, 1, 1), 4, Cn ** -0.5), rnd((Cn,), 5, 0.1)
+    dy = rnd((N, H, W, Cn), 6)
+
+    def run(fused):
+        t = [v.to(DEV).requires_grad_(True) for v in (x, wqkv, bqkv, wp, bp)]
+        if fused:
+            y = ops.NormLocalAttentionFn.apply(*t)
+        else:
+            y = ops.LocalAttentionFusedFn.apply(ops.instnorm_act(t[0], ops.ACT_RELU), *t[1:])
+        y.backward(dy.to(DEV))
+        return y.detach().cpu(), [v.grad.cpu() for v in t]
+
+    yf, gf = run(True)
+    yc, gc = run(False)
+    assert torch.equal(yf, yc), "fused forward is not bit-identical to the chain"
+    for name, a, b in zip(("dx", "dwqkv", "dbqkv", "dwp", "dbp"), gf, gc):
+        report(f"norm+attn C{Cn} N{N} {H}x{W} {name} vs chain", rel_l2(a, b), 2e-6)
+    # the oracle's restatement (torch fp32 on the CPU) of IN -> ReLU -> LocalAttention
+    from oracle import restatement as R
+    t = [v.clone().requires_grad_(True) for v in (x, wqkv, bqkv, wp, bp)]
+    sd = {"a.qkv.weight": t[1], "a.qkv.bias": t[2], "a.proj.weight": t[3], "a.proj.bias": t[4]}
+    yt = R.local_attention(F.relu(R.instance_norm(t[0].permute(0, 3, 1, 2))), sd, "a").permute(0, 2, 3, 1)
+    yt.backward(dy)
+    report(f"norm+attn C{Cn} N{N} {H}x{W} y vs oracle", rel_l2(yf, yt.detach()), 2e-5)
+    for name, a, b in zip(("dx", "dwqkv", "dbqkv", "dwp", "dbp"), gf, [v.grad for v in t]):
+        report(f"norm+attn C{Cn} N{N} {H}x{W} {name} vs oracle", rel_l2(a, b), 5e-5)
+
+
+def test_norm_attention_many_images_per_wave():
+    """More windows than waves, and images whose windows are not a multiple of the grid: every (image, wave) row of the norm
+    sums is either written or skipped by the reduce kernel."""
+    from mstg_hip import ops
+    N, H, W, Cn = 37, 36, 20, 16   # 45 windows per image, 1665 windows < 2048 waves; and a case above
+    for (N, H, W) in ((37, 36, 20), (9, 100, 92)):
+        x = rnd((N, H, W, Cn), 11, 1.5)
+        params = [rnd((3 * Cn, Cn, 1, 1), 2, 0.25), rnd((3 * Cn,), 3, 0.1), rnd((Cn, Cn, 1, 1), 4, 0.25), rnd((Cn,), 5, 0.1)]
+        dy = rnd((N, H, W, Cn), 6)
+        outs = []
+        for fused in (True, False):
+            t = [v.to(DEV).requires_grad_(True) for v in [x] + params]
+            y = (ops.NormLocalAttentionFn.apply(*t) if fused
+                 else ops.LocalAttentionFusedFn.apply(ops.instnorm_act(t[0], ops.ACT_RELU), *t[1:]))
+            y.backward(dy.to(DEV))
+            outs.append((y.detach().cpu(), t[0].grad.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        report(f"norm+attn N{N} {H}x{W} dx vs chain", rel_l2(outs[0][1], outs[1][1]), 2e-6)
