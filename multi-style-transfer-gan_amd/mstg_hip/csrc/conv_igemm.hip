@@ -12,34 +12,11 @@
 // Reference sites replaced: every nn.Conv2d / nn.ConvTranspose2d forward and the dgrad half of their autograd
 // (enhanced_generator.py:10-11,53-73,92,99,106,121,128,137,237-265; pretrain.py:65-91).
 #include "common.h"
+#include "igemm_args.h"
 #include <stdlib.h>
 
 namespace mstg {
 
-struct IGemmArgs {
-    const float* x;
-    float* y;
-    const float* w;
-    const float* bias;
-    int N;
-    int H, W, x_ctot, x_coff, x_nchw;   // source tensor
-    int Cr;                             // reduction channels
-    int Ho, Wo, y_ctot, y_coff, y_nchw; // destination tensor
-    int Co;                             // output channels
-    int Gh, Gw;                         // grid walked by the tiles (Ho x Wo, or the source grid in phase mode)
-    int tiles_x, tiles_y;
-    int KH, KW, stride, pad, dil, flip, phase;
-    int w_so, w_sr;                     // weight strides of the output / reduction channel (taps are innermost)
-    int PH, PW;                         // LDS patch extent
-    int TG;                             // taps per weight-staging group
-    int ntaps;
-    int act, accumulate;
-    int dbg;
-    int psz;           // stream kernel: floats reserved for the LDS patch (>= the dpack exchange tiles)
-    int wglob;         // light kernel: filter fragments straight from the packed filter in L2 (no LDS filter slice)
-    int TH;            // tile height in grid rows: 8, or 16 where the light kernel gives each wave four rows
-    int dpack, tapsx;  // <= 4 output channels: rows of the MFMA tile = (pixel shift delta, channel), see igemm_light_kernel
-};
 
 constexpr int TILE_H = 8, TILE_W = 16;
 
@@ -1063,10 +1040,12 @@ static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
 size_t igemm_workspace_bytes(IGemmArgs a) {
     IGemmPlan p;
     if (plan_igemm(a, p)) return 0;
-    return p.ws_bytes;
+    const size_t alt = p32_workspace_bytes(a);  // the persistent kernel packs its filter differently (conv_p32.hip)
+    return p.ws_bytes > alt ? p.ws_bytes : alt;
 }
 
 int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (p32_eligible(a)) return launch_p32(a, workspace, workspace_bytes, st);  // 4x4 stride-2 family at 16 / 32 / 64 channels
     a.dbg = 0;
     IGemmPlan p;
     if (int rc = plan_igemm(a, p)) return rc;
@@ -1201,6 +1180,7 @@ const char* igemm_kernel_name(const mstg_conv_desc* d, int pass) {
     if (pass == 0) fill_fwd_args(d, a);
     else if (fill_dgrad_args(d, a)) return "";
     if (plan_igemm(a, p)) return "";
+    if (p32_eligible(a)) return p32_kernel_name(a);
     if (p.stream) snprintf(name, sizeof(name), "igemm_stream_kernel<%d, %d, %d, %d>", p.V, p.nfw, p.pf, p.src);
     else if (p.heavy) snprintf(name, sizeof(name), "igemm_heavy_kernel<%d, %d, %d>", p.V, p.nfw, p.src);
     else snprintf(name, sizeof(name), "igemm_light_kernel<%d, %d, %d>", p.V, p.nfw, p.pf);

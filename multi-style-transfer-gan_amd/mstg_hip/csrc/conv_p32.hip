@@ -1,0 +1,398 @@
+// Persistent, software-pipelined implicit-GEMM kernel for the 4x4 stride-2 family on the fp32 MFMA (v_mfma_f32_16x16x4_f32):
+// Conv2d(k4,s2,p1) forward, ConvTranspose2d(k4,s2,p1) forward (four output-parity classes, each a 2x2 stride-1 gather) and
+// their input gradients (each is the other's shape with the weight read through swapped strides) at 16 / 32 / 64 channels on
+// both sides -- the down / up convolutions of every generator stage and the discriminator body (enhanced_generator.py:92, 99,
+// 121, 128, 240-247), forward and dgrad.
+//
+// Why a second kernel: igemm_light_kernel gives a workgroup ONE tile and relies on 3-5 co-resident workgroups to hide the
+// patch round trip behind somebody else's MFMAs; PMC counters put its matrix pipe at 24-46 % busy on these layers.  Here a
+// workgroup is persistent and overlaps the phases itself (the design of the fp16 inference kernel, infer_f16.hip):
+//     registers (prefetched patch of the NEXT tile) -> LDS | barrier | issue the loads of the tile after |
+//     K-steps: LDS offset of step s+2 | operand fragments of step s+1 | 4 * RPW * NF MFMAs of step s | epilogue | barrier
+// A K-step is one tap x 16 source channels: lane (n = pixel column, g) reads the 16 bytes of channels 4g..4g+3 of its pixel at
+// that tap (one ds_read_b128 per tile row) and the matching filter quads; MFMA j of the step multiplies element j of both.
+// The per-step tap offsets live in an LDS table (a dynamically indexed kernel argument would be a scalar load whose wait also
+// drains the LDS reads in flight).  LDS pixel stride = 4 Cin + 16 bytes for the stride-2 gather and 4 Cin + 32 for the
+// stride-1 classes: conflict-free for ds_read_b128's lane grouping.  The packed filter [step][fragment][lane][4] sits in LDS
+// when it fits beside the patch at two workgroups per CU, else its fragments are read lane-linear from L2.
+#include <stdlib.h>
+
+#include "igemm_args.h"
+
+namespace mstg {
+namespace {
+
+struct TrueT { static constexpr bool value = true; };
+struct FalseT { static constexpr bool value = false; };
+
+constexpr int P32_MAX_STEPS = 64;
+constexpr int P32_MAX_SEG = 4;
+constexpr int P32_TW = 16;
+constexpr int P32_TABLE_BYTES = P32_MAX_STEPS * 4 + P32_MAX_SEG * 16;
+
+struct P32Plan {
+    int nsteps, nseg;
+    struct Seg { int s0, s1, oy, ox; } seg[P32_MAX_SEG];  // one segment per output-parity class (one in all for the stride-2 gather)
+    unsigned koff[P32_MAX_STEPS];                          // byte offset of the step's tap / channel chunk from the lane's pixel base
+    int8_t tky[P32_MAX_STEPS], tkx[P32_MAX_STEPS];         // filter tap of the step
+    int16_t tcb[P32_MAX_STEPS];                            // first source channel of the step
+    int PH, PW, pixstride, oy0, ox0, stride, up, NF, TH, npf, wlds;
+    unsigned m_pw, m_ntile, m_tx;
+};
+
+struct P32Args {
+    const float* x;
+    float* y;
+    const float* wpk;   // [step][frag][lane][4]
+    const float* bias;  // [16 * NF], zeros for an input gradient
+    int N, H, W, Cin, Ho, Wo, Cout, Gh, Gw, tiles_x, tiles_y, dbg;
+};
+
+// ---- filter pack: PyTorch layout (through the gather's strides) -> MFMA A-fragment order ---------------------------------------
+__global__ void p32_pack_kernel(const P32Plan p, const float* __restrict__ w, const float* __restrict__ bias, int w_so, int w_sr,
+                                int Cout, int Cin, float* __restrict__ wpk, float* __restrict__ bpk) {
+    const int total = p.nsteps * p.NF * 64 * 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int j = e & 3, lane = (e >> 2) & 63, sf = e >> 8, f = sf % p.NF, s = sf / p.NF;
+        const int co = 16 * f + (lane & 15), ci = p.tcb[s] + 4 * (lane >> 4) + j;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[(size_t)co * w_so + (size_t)ci * w_sr + p.tky[s] * 4 + p.tkx[s]];
+        wpk[e] = v;
+    }
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 16 * p.NF; c += gridDim.x * blockDim.x) bpk[c] = (bias && c < Cout) ? bias[c] : 0.f;
+}
+
+template <int NPF>
+struct P32Regs {
+    f32x4 v[NPF];
+    unsigned okmask;
+};
+
+__device__ __forceinline__ int p32_tile(int it, int b, int G) { return it * G + (b & 7) * (G >> 3) + (b >> 3); }  // XCD-contiguous
+
+template <int NPF>
+__device__ __forceinline__ void p32_fetch(const P32Args& a, const P32Plan& p, int t, int TH, int tid, const unsigned (&rel)[NPF],
+                                          unsigned vmask, P32Regs<NPF>& R) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+    const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+    const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * P32_TW * p.stride + p.ox0;
+    const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + p.PH <= a.H && sx0 + p.PW <= a.W;  // uniform
+    const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 4;
+    if (interior) {
+        const char* org = img + ((size_t)sy0 * a.W + sx0) * a.Cin * 4;
+        R.okmask = vmask;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) R.v[k] = *reinterpret_cast<const f32x4*>(org + (((vmask >> k) & 1) ? rel[k] : 0u));
+    } else {
+        R.okmask = 0;
+        const long org = ((long)sy0 * a.W + sx0) * a.Cin * 4;
+        const int quads = a.Cin >> 2, sh = quads == 4 ? 2 : (quads == 8 ? 3 : 4);
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {  // border tile: recompute the pixel instead of keeping (r, c) in registers
+            const int pix = (256 * k + tid) >> sh;
+            const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
+            const int iy = sy0 + r, ix = sx0 + c;
+            const bool ok = ((vmask >> k) & 1) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            R.okmask |= (unsigned)ok << k;
+            R.v[k] = *reinterpret_cast<const f32x4*>(img + (ok ? org + (long)rel[k] : 0L));
+        }
+    }
+}
+
+template <int RPW, int NF, int NPF, bool WLDS>
+__global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P32Plan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TH = 4 * RPW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, g = lane >> 4;
+    const int ntile = a.tiles_x * a.tiles_y, total_tiles = a.N * ntile, G = gridDim.x;
+    unsigned char* wl = smem + P32_TABLE_BYTES;
+    unsigned char* patch = wl + (WLDS ? (size_t)p.nsteps * NF * 1024 : 0);
+    if (tid < P32_MAX_STEPS) {
+        reinterpret_cast<unsigned*>(smem)[tid] = p.koff[tid];
+    } else if (tid < P32_MAX_STEPS + P32_MAX_SEG) {
+        const int c = tid - P32_MAX_STEPS;
+        int* e = reinterpret_cast<int*>(smem + 4 * P32_MAX_STEPS + 16 * c);
+        e[0] = p.seg[c].s0; e[1] = p.seg[c].s1; e[2] = p.seg[c].oy; e[3] = p.seg[c].ox;
+    }
+    if (WLDS) {
+        const int nchunk = p.nsteps * NF * 64;
+        for (int e = tid; e < nchunk; e += 256) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(a.wpk)[e];
+    }
+    const f32x4* wglob = reinterpret_cast<const f32x4*>(a.wpk) + lane;  // static address spaces: no flat loads
+    const unsigned char* wlds_lane = wl + 16 * lane;
+    const int nseg = p.nseg, up = p.up;
+    unsigned base[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) base[r] = (unsigned)(((RPW * wv + r) * p.stride * p.PW + nl * p.stride) * p.pixstride + 16 * g);
+    f32x4 b4[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b4[f] = *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
+
+    // what a thread stages is the same for every tile: element k of thread tid = channel quad o of patch pixel (r, c)
+    const int quads = a.Cin >> 2, o = tid & (quads - 1), sh = quads == 4 ? 2 : (quads == 8 ? 3 : 4);
+    unsigned rel[NPF], vmask = 0;
+    {
+        const int total = p.PH * p.PW * quads;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = 256 * k + tid, pix = e >> sh;
+            const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
+            if (e < total) vmask |= 1u << k;
+            rel[k] = (unsigned)(((r * a.W + c) * a.Cin + 4 * o) * 4);
+        }
+    }
+    const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 4;  // bytes between this wave's consecutive rows
+    P32Regs<NPF> R;
+    int it = 0;
+    int t = p32_tile(it, blockIdx.x, G);
+    if (t < total_tiles) p32_fetch<NPF>(a, p, t, TH, tid, rel, vmask, R);
+    while (t < total_tiles) {
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+        const int gy0 = ty * TH, gx0 = tx * P32_TW;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            if ((vmask >> k) & 1) {
+                f32x4 w = R.v[k];
+                if (!((R.okmask >> k) & 1)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;
+            }
+        __syncthreads();
+        const int tnext = p32_tile(it + 1, blockIdx.x, G);
+        if (tnext < total_tiles) p32_fetch<NPF>(a, p, tnext, TH, tid, rel, vmask, R);
+
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int4 ci = *reinterpret_cast<const int4*>(smem + 4 * P32_MAX_STEPS + 16 * sg);
+            const int s0 = __builtin_amdgcn_readfirstlane(ci.x), s1 = __builtin_amdgcn_readfirstlane(ci.y);
+            const int oyc = __builtin_amdgcn_readfirstlane(ci.z), oxc = __builtin_amdgcn_readfirstlane(ci.w);
+            f32x4 acc[RPW][NF];
+            auto load_ko = [&](int s) -> unsigned { return reinterpret_cast<const unsigned*>(smem)[s]; };
+            auto load_ops = [&](unsigned ko, int s, f32x4 (&bf)[RPW], f32x4 (&af)[NF]) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) bf[r] = *reinterpret_cast<const f32x4*>(patch + base[r] + ko);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (WLDS) af[f] = *reinterpret_cast<const f32x4*>(wlds_lane + (size_t)(s * NF + f) * 1024);
+                    else af[f] = wglob[(size_t)(s * NF + f) * 64];
+                }
+            };
+            auto mma_step = [&](const f32x4 (&bf)[RPW], const f32x4 (&af)[NF], auto from_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+                            acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f][j], bf[r][j],
+                                                                             (decltype(from_bias)::value && j == 0) ? b4[f] : acc[r][f], 0, 0, 0);
+            };
+            auto clip = [&](int s) { return s < s1 ? s : s1 - 1; };  // past the end: re-read the last step (loaded, never used)
+            f32x4 bA[RPW], aA[NF], bB[RPW], aB[NF];
+            unsigned k0 = load_ko(s0), k1 = load_ko(clip(s0 + 1));
+            load_ops(k0, s0, bA, aA);
+            k0 = load_ko(clip(s0 + 2));
+            load_ops(k1, clip(s0 + 1), bB, aB);
+            mma_step(bA, aA, TrueT{});  // accumulators start from the bias (the MFMA's C operand)
+            int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), k0 the offset of step s + 1
+            for (; s + 1 < s1; s += 2) {
+                k1 = load_ko(clip(s + 2));
+                load_ops(k0, s + 1, bA, aA);
+                mma_step(bB, aB, FalseT{});
+                k0 = load_ko(clip(s + 3));
+                load_ops(k1, clip(s + 2), bB, aB);
+                mma_step(bA, aA, FalseT{});
+            }
+            if (s < s1) mma_step(bB, aB, FalseT{});
+            // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) --------
+            const int mul = up ? 2 : 1;
+            if (gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw && (a.Cout & 15) == 0) {
+                char* ybase = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
+                const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 4u;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(ybase + r * out_row + out_off0 + 64 * f) = acc[r][f];
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int gy = gy0 + RPW * wv + r, gx = gx0 + nl;
+                    if (gy < a.Gh && gx < a.Gw) {
+                        const int oy = gy * mul + oyc, ox = gx * mul + oxc;
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+                            if (16 * f + 4 * g < a.Cout)
+                                *reinterpret_cast<f32x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g) = acc[r][f];
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the patch
+        ++it;
+        t = tnext;
+    }
+}
+
+}  // namespace
+
+// ---- host -------------------------------------------------------------------------------------------------------------------
+static int p32_plan(const IGemmArgs& a, P32Plan& p);
+
+bool p32_eligible(const IGemmArgs& a) {
+    const char* e = env_get(ENV_P32);
+    if (e && e[0] == '0') return false;
+    auto ch_ok = [](int c) { return c == 16 || c == 32 || c == 64; };
+    if (a.x_nchw || a.y_nchw || a.x_coff || a.y_coff || a.x_ctot != a.Cr || a.y_ctot != a.Co) return false;
+    if (!ch_ok(a.Cr) || !ch_ok(a.Co)) return false;
+    if (a.KH != 4 || a.KW != 4 || a.dil != 1 || a.flip || a.accumulate || a.act != MSTG_ACT_NONE) return false;
+    if (a.phase ? !(a.Ho == 2 * a.H && a.Wo == 2 * a.W) : !(a.stride == 2 && a.pad == 1 && a.H == 2 * a.Ho && a.W == 2 * a.Wo)) return false;
+    P32Plan p;
+    return p32_plan(a, p) == MSTG_OK;  // e.g. a 64-channel stride-2 patch does not fit the prefetch registers: igemm_light takes it
+}
+
+static int p32_plan(const IGemmArgs& a, P32Plan& p) {
+    memset(&p, 0, sizeof(p));
+    const int Cin = a.Cr, nchunk = Cin / 16;
+    p.NF = a.Co / 16;
+    p.up = a.phase ? 1 : 0;
+    p.stride = p.up ? 1 : 2;
+    p.pixstride = 4 * Cin + (p.up ? 32 : 16);
+    const int halo_lo = -1, halo_hi = p.up ? 1 : 2;  // gather rows y*s - 1 ... y*s + 2 (stride 2) / y - 1 ... y + 1 (classes)
+    const int ext = halo_hi - halo_lo;
+    p.PW = (P32_TW - 1) * p.stride + 1 + ext;
+    p.oy0 = p.ox0 = halo_lo;
+    int s = 0;
+    if (!p.up) {
+        p.nseg = 1;
+        p.seg[0].s0 = 0;
+        for (int ky = 0; ky < 4; ++ky)
+            for (int kx = 0; kx < 4; ++kx)
+                for (int c = 0; c < nchunk; ++c, ++s) {
+                    p.koff[s] = (unsigned)((ky * p.PW + kx) * p.pixstride + 64 * c);
+                    p.tky[s] = (int8_t)ky; p.tkx[s] = (int8_t)kx; p.tcb[s] = (int16_t)(16 * c);
+                }
+        p.seg[0].s1 = s;
+    } else {
+        p.nseg = 4;
+        for (int cls = 0; cls < 4; ++cls) {
+            const int py = cls >> 1, px = cls & 1;
+            p.seg[cls].s0 = s; p.seg[cls].oy = py; p.seg[cls].ox = px;
+            for (int aa = 0; aa < 2; ++aa)
+                for (int bb = 0; bb < 2; ++bb) {
+                    // output row 2y + py gathers source rows y - 1 (ky = 3), y (ky = 1) for py = 0 and y (ky = 2), y + 1 (ky = 0) for py = 1
+                    const int dyy = py == 0 ? aa - 1 : aa, ky = py == 0 ? (aa == 0 ? 3 : 1) : (aa == 0 ? 2 : 0);
+                    const int dxx = px == 0 ? bb - 1 : bb, kx = px == 0 ? (bb == 0 ? 3 : 1) : (bb == 0 ? 2 : 0);
+                    for (int c = 0; c < nchunk; ++c, ++s) {
+                        p.koff[s] = (unsigned)(((dyy + 1) * p.PW + dxx + 1) * p.pixstride + 64 * c);
+                        p.tky[s] = (int8_t)ky; p.tkx[s] = (int8_t)kx; p.tcb[s] = (int16_t)(16 * c);
+                    }
+                }
+            p.seg[cls].s1 = s;
+        }
+    }
+    if (s > P32_MAX_STEPS) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: too many K-steps");
+    p.nsteps = s;
+    // tile height and where the filter lives: two workgroups per CU (<= 78 KiB each) with the filter in LDS if possible
+    const size_t wb = (size_t)p.nsteps * p.NF * 1024;
+    auto patch_bytes_of = [&](int th) {
+        const int ph = (th - 1) * p.stride + 1 + ext;
+        return cdiv(ph * p.PW * (Cin / 4), 256) > 12 ? (size_t)1 << 30 : (size_t)ph * p.PW * p.pixstride;
+    };
+    int TH = 0, wlds = 0;
+    const int cand[3] = {16, 8, 4};
+    for (int pass = 0; pass < 2 && !TH; ++pass)
+        for (int k = 0; k < 3 && !TH; ++k) {
+            const size_t need = P32_TABLE_BYTES + patch_bytes_of(cand[k]) + (pass == 0 ? wb : 0);
+            if (need <= 78 * 1024 && !(p.NF == 4 && cand[k] == 16)) { TH = cand[k]; wlds = pass == 0; }
+        }
+    if (!TH) { TH = 4; wlds = 0; }
+    { const char* e = env_get(ENV_P32_TH); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16) && !(p.NF == 4 && atoi(e) == 16)) TH = atoi(e); }
+    { const char* e = env_get(ENV_P32_WLDS); if (e) wlds = atoi(e) != 0; }
+    if (patch_bytes_of(TH) >= ((size_t)1 << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: patch needs more than 12 prefetch registers");
+    if (P32_TABLE_BYTES + patch_bytes_of(TH) + (wlds ? wb : 0) > 156 * 1024) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: LDS budget");
+    p.TH = TH; p.wlds = wlds;
+    p.PH = (TH - 1) * p.stride + 1 + ext;
+    p.m_pw = magic_u32((unsigned)p.PW);
+    p.npf = cdiv(p.PH * p.PW * (Cin / 4), 256);
+    return MSTG_OK;
+}
+
+size_t p32_workspace_bytes(const IGemmArgs& a) {
+    P32Plan p;
+    if (!p32_eligible(a) || p32_plan(a, p)) return 0;  // (eligible implies a plan)
+    return 256 + (size_t)p.nsteps * p.NF * 1024;
+}
+
+template <int RPW, int NF, int NPF>
+static int p32_launch_t(const P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st) {
+    auto kern = p.wlds ? conv_p32_kernel<RPW, NF, NPF, true> : conv_p32_kernel<RPW, NF, NPF, false>;
+    const void* kptr = reinterpret_cast<const void*>(kern);
+    static const void* c_kern = nullptr;
+    static size_t c_lds = 0;
+    static int c_occ = 1;
+    if (c_kern != kptr || c_lds != lds) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kptr, 256, lds) != hipSuccess || nb < 1) nb = 1;
+        c_occ = nb > 4 ? 4 : nb;
+        c_kern = kptr;
+        c_lds = lds;
+    }
+    long g_ = 256L * c_occ;
+    if (g_ > tiles) g_ = (tiles + 7) & ~7L;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
+    MSTG_CHECK_LAUNCH("conv_p32_kernel");
+    return MSTG_OK;
+}
+
+template <int RPW, int NF>
+static int p32_launch_npf(const P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st) {
+    if (p.npf <= 4) return p32_launch_t<RPW, NF, 4>(a, p, lds, tiles, st);
+    if (p.npf <= 6) return p32_launch_t<RPW, NF, 6>(a, p, lds, tiles, st);
+    if (p.npf <= 8) return p32_launch_t<RPW, NF, 8>(a, p, lds, tiles, st);
+    if (p.npf <= 10) return p32_launch_t<RPW, NF, 10>(a, p, lds, tiles, st);
+    return p32_launch_t<RPW, NF, 12>(a, p, lds, tiles, st);
+}
+
+int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    P32Plan p;
+    if (int rc = p32_plan(g, p)) return rc;
+    const size_t need = 256 + (size_t)p.nsteps * p.NF * 1024;
+    if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "conv_p32: workspace too small for the packed filter");
+    P32Args a;
+    a.x = g.x; a.y = g.y;
+    a.bias = (const float*)workspace;
+    a.wpk = (const float*)((const char*)workspace + 256);
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cr; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Co;
+    a.Gh = p.up ? g.H : g.Ho;
+    a.Gw = p.up ? g.W : g.Wo;
+    a.tiles_y = cdiv(a.Gh, p.TH);
+    a.tiles_x = cdiv(a.Gw, P32_TW);
+    { const char* e = env_get(ENV_P32_DBG); a.dbg = e ? atoi(e) : 0; }
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    if ((unsigned long long)(tiles + 4096) * (unsigned long long)(a.tiles_x * a.tiles_y) >= (1ull << 32) || (size_t)g.H * g.W * g.Cr * 4 >= (1ull << 32))
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: tensor too large for the 32-bit tile / offset arithmetic");
+    p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
+    p.m_tx = magic_u32((unsigned)a.tiles_x);
+    hipLaunchKernelGGL(p32_pack_kernel, dim3(32), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_CHECK_LAUNCH("p32_pack_kernel");
+    size_t lds = P32_TABLE_BYTES + (size_t)p.PH * p.PW * p.pixstride + (p.wlds ? (size_t)p.nsteps * p.NF * 1024 : 0);
+    lds = (lds + 15) & ~(size_t)15;
+#define MSTG_P32_CASE(R_, F_) if (p.TH == 4 * R_ && p.NF == F_) return p32_launch_npf<R_, F_>(a, p, lds, tiles, st);
+    MSTG_P32_CASE(1, 1) MSTG_P32_CASE(2, 1) MSTG_P32_CASE(4, 1)
+    MSTG_P32_CASE(1, 2) MSTG_P32_CASE(2, 2) MSTG_P32_CASE(4, 2)
+    MSTG_P32_CASE(1, 4) MSTG_P32_CASE(2, 4)
+#undef MSTG_P32_CASE
+    return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: no kernel variant");
+}
+
+const char* p32_kernel_name(const IGemmArgs& a) {
+    static thread_local char name[64];
+    P32Plan p;
+    if (p32_plan(a, p)) return "";
+    snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s>", p.TH / 4, p.NF, p.npf <= 4 ? 4 : (p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : (p.npf <= 10 ? 10 : 12))),
+             p.wlds ? "true" : "false");
+    return name;
+}
+
+}  // namespace mstg

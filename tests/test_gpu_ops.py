@@ -76,6 +76,17 @@ CONV_CASES = [
     ("k4s1p1 64->1 (D head)", 2, 4, 4, 64, 1, 4, 1, 1, 1, 0, 0, 0, 0),
     ("k4s1p1 128->1 16x16", 2, 16, 16, 128, 1, 4, 1, 1, 1, 0, 0, 0, 0),
     ("k3 d1 ragged 13x21 4->5", 1, 13, 21, 4, 5, 3, 1, 1, 1, 0, 0, 0, 0),
+    # the persistent kernel of the 4x4 stride-2 family (conv_p32.hip): every channel pairing class, ragged tiles, several images
+    ("p32 k4s2 16->16 ragged 20x36 N3", 3, 20, 36, 16, 16, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("p32 k4s2 64->64 24x40", 2, 24, 40, 64, 64, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("p32 k4s2 64->16 70x34", 1, 70, 34, 64, 16, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("p32 k4s2 32->32 128x128", 1, 128, 128, 32, 32, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("p32 k4s2 16->64 2x2", 2, 2, 2, 16, 64, 4, 2, 1, 1, 0, 0, 0, 0),
+    ("p32 convT 16->64 ragged 5x7", 1, 5, 7, 16, 64, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("p32 convT 64->64 9x11", 2, 9, 11, 64, 64, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("p32 convT 16->16 17x33 N3", 3, 17, 33, 16, 16, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("p32 convT 32->32 64x64", 1, 64, 64, 32, 32, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("p32 convT 64->16 1x1", 2, 1, 1, 64, 16, 4, 2, 1, 1, 1, 0, 0, 0),
 ]
 
 
@@ -203,7 +214,8 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
 
 
 @pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
-                                 "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0"])
+                                 "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0",
+                                 "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1"])
 def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
@@ -213,7 +225,8 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     test_conv_channel_slices_and_accumulate(2, 21, 37, 16)
     test_conv_channel_slices_and_accumulate(1, 32, 32, 32)
     for case in CONV_CASES:
-        if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4"):
+        if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4") or (k.startswith("MSTG_P32") and (
+                case[0].startswith("p32") or case[0].startswith("convT") or case[0].startswith("k4s2"))):
             test_conv_fwd_bwd(case)
     if k == "MSTG_ATTN_BLK64":
         test_window_attention_core(2, 8, 8, 64)

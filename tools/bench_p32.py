@@ -1,0 +1,53 @@
+"""GPU box: the persistent 4x4 stride-2 kernel (conv_p32.hip) against igemm_light on the layers of the headline step.
+usage: python tools/bench_p32.py   (prints ms per launch for MSTG_P32=0 / default / forced variants)"""
+import os
+import sys
+import torch
+sys.path.insert(0, "multi-style-transfer-gan_amd")
+from mstg_hip import ops
+
+dev = "cuda:0"
+# (tag, N, H, W, Cin, Cout, transposed)
+LAYERS = [("down1 16->32", 64, 256, 256, 16, 32, 0), ("down2 32->64", 64, 128, 128, 32, 64, 0), ("up1 T 64->32", 64, 64, 64, 64, 32, 1),
+          ("up2 T 32->16", 64, 128, 128, 32, 16, 1), ("D 16->32", 32, 128, 128, 16, 32, 0), ("D 32->64", 32, 64, 64, 32, 64, 0)]
+
+
+def time_it(fn, reps=10):
+    for _ in range(3):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        fn()
+    ev[1].record()
+    torch.cuda.synchronize()
+    return ev[0].elapsed_time(ev[1]) / reps
+
+
+def run(tag_env):
+    for k in ("MSTG_P32", "MSTG_P32_TH", "MSTG_P32_WLDS"):
+        os.environ.pop(k, None)
+    for kv in tag_env.split():
+        k, v = kv.split("=")
+        os.environ[k] = v
+    ops.refresh_env()
+    out = []
+    for tag, N, H, W, Ci, Co, tr in LAYERS:
+        Ho, Wo = (2 * H, 2 * W) if tr else (H // 2, W // 2)
+        x = torch.randn(N, H, W, Ci, device=dev)
+        w = torch.randn((Ci, Co, 4, 4) if tr else (Co, Ci, 4, 4), device=dev) * 0.05
+        b = torch.randn(Co, device=dev)
+        y = torch.empty(N, Ho, Wo, Co, device=dev)
+        dy = torch.randn_like(y)
+        dx = torch.empty_like(x)
+        d = ops.make_desc(N, H, W, Ci, Ho, Wo, Co, 4, 2, 1, 1, transposed=tr)
+        tf = time_it(lambda: ops.conv_fwd_raw(d, x, w, b, y))
+        tb = time_it(lambda: ops.conv_dgrad_raw(d, dy, w, dx))
+        fl = 2.0 * N * (Ho * Wo if not tr else H * W * 4) * Co * Ci * (16 if not tr else 4)
+        out.append(f"{tag:14s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)")
+    print(f"--- {tag_env or 'default'}")
+    print("\n".join(out), flush=True)
+
+
+for env in sys.argv[1:] or ["MSTG_P32=0", "", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=0 MSTG_P32_TH=8"]:
+    run(env)
