@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         const int gy0 = ty * TH, gx0 = tx * P32_TW;
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
-            if ((vmask >> k) & 1) {
+            if (((vmask >> k) & 1) && !(a.dbg & 8)) {
                 f32x4 w = R.v[k];
                 if (!((R.okmask >> k) & 1)) w = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;
             }
         __syncthreads();
         const int tnext = p32_tile(it + 1, blockIdx.x, G);
-        if (tnext < total_tiles) p32_fetch<NPF>(a, p, tnext, TH, tid, rel, vmask, R);
+        if (tnext < total_tiles && !(a.dbg & 4)) p32_fetch<NPF>(a, p, tnext, TH, tid, rel, vmask, R);
 
         for (int sg = 0; sg < nseg; ++sg) {
             const int4 ci = *reinterpret_cast<const int4*>(smem + 4 * P32_MAX_STEPS + 16 * sg);
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             load_ops(k1, clip(s0 + 1), bB, aB);
             mma_step(bA, aA, TrueT{});  // accumulators start from the bias (the MFMA's C operand)
             int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), k0 the offset of step s + 1
+            if (a.dbg & 1) s = s1;  // experiments (MSTG_P32_DBG): 1 one K-step only, 2 no stores, 4 no patch fetch, 8 no patch commit
             for (; s + 1 < s1; s += 2) {
                 k1 = load_ko(clip(s + 2));
                 load_ops(k0, s + 1, bA, aA);
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             if (s < s1) mma_step(bB, aB, FalseT{});
             // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) --------
             const int mul = up ? 2 : 1;
+            if (a.dbg & 2) continue;
             if (gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw && (a.Cout & 15) == 0) {
                 char* ybase = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
                 const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 4u;

@@ -422,6 +422,126 @@ __global__ __launch_bounds__(256, 3) void wgrad_ts_kernel(const WGradArgs a, con
 }
 
 // =====================================================================================================================
+// Persistent form of the tap-split kernel for the 4x4 stride-2 family (aligned NHWC on both sides, gathered channels in chunks
+// of 16, grid channels in groups of 32): the workgroup fetches the NEXT tile's patch and grid tile into registers before it
+// starts on the current tile's MFMAs, so the global round trip (a third of a tile's time in wgrad_ts_kernel, time stamps in
+// DESIGN.md) runs behind the arithmetic instead of in front of it.  Same LDS layouts, same unit dealing, same partial-slab
+// layout and reduce kernel as wgrad_ts_kernel.
+// =====================================================================================================================
+constexpr int WP_TH = 4, WP_NFHT = 2, WP_UW = 8, WP_NG = 6, WP_NH = 2;  // 10 x 34 x 4 patch quads = 5.3 per thread; 64 x 8 tile quads = 2
+
+struct WpRegs {
+    f32x4 gv[WP_NG], hv[WP_NH];
+    unsigned gok, hok;
+};
+
+// element k of thread tid: patch quad e = 256 k + tid -> pixel e >> 2 = (pr, pc), channel quad e & 3; tile quad -> pixel e >> 3, quad e & 7.
+// Offsets are recomputed per tile (a few integer instructions against ~4000 MFMA cycles) rather than held in registers.
+__device__ __forceinline__ void wp_fetch(const WGradArgs& a, int tile, int tid, int g0, int h0, unsigned m_pw, WpRegs& R) {
+    const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
+    const int y0 = ty0 * WP_TH * 2 - 1, x0 = tx0 * WT_W * 2 - 1;
+    const char* gimg = reinterpret_cast<const char*>(a.g + (size_t)n * a.gH * a.gW * a.Cg + g0);
+    const char* himg = reinterpret_cast<const char*>(a.h + (size_t)n * a.hH * a.hW * a.Ch + h0);
+    const bool gin = y0 >= 0 && x0 >= 0 && y0 + a.PH <= a.gH && x0 + a.PW <= a.gW;  // uniform
+    const int total = a.PH * a.PW * 4;
+    R.gok = 0;
+#pragma unroll
+    for (int k = 0; k < WP_NG; ++k) {
+        const int e = 256 * k + tid, pix = e >> 2;
+        const int pr = (int)__umulhi((unsigned)pix, m_pw), pc = pix - pr * a.PW;
+        const bool ok = e < total && (gin || ((unsigned)(y0 + pr) < (unsigned)a.gH && (unsigned)(x0 + pc) < (unsigned)a.gW));
+        R.gok |= (unsigned)ok << k;
+        const unsigned off = ok ? (unsigned)((((y0 + pr) * a.gW + x0 + pc) * a.Cg + 4 * (e & 3)) * 4) : 0u;
+        R.gv[k] = *reinterpret_cast<const f32x4*>(gimg + off);
+    }
+    const int gy0 = ty0 * WP_TH, gx0 = tx0 * WT_W;
+    R.hok = 0;
+#pragma unroll
+    for (int k = 0; k < WP_NH; ++k) {
+        const int e = 256 * k + tid, pix = e >> 3;
+        const bool ok = gy0 + (pix >> 4) < a.hH && gx0 + (pix & 15) < a.hW;
+        R.hok |= (unsigned)ok << k;
+        const unsigned off = ok ? (unsigned)((((gy0 + (pix >> 4)) * a.hW + gx0 + (pix & 15)) * a.Ch + 4 * (e & 7)) * 4) : 0u;
+        R.hv[k] = *reinterpret_cast<const f32x4*>(himg + off);
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void wgrad_p32_kernel(const WGradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TH = WP_TH, NFHT = WP_NFHT, UW = WP_UW, BNP = 16 * NFHT + 4;
+    const int ckp = a.ckp;
+    float* patch = smem;                                // [PH][PW][ckp]
+    float* ht = smem + ((a.PH * a.PW * ckp + 3) & ~3);  // [TH*16][BNP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    const int gchunk = blockIdx.y % a.n_gchunks, hgroup = blockIdx.y / a.n_gchunks;
+    const int g0 = gchunk * 16, h0 = hgroup * 16 * NFHT;
+    f32x4 acc[UW];
+#pragma unroll
+    for (int k = 0; k < UW; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // unit u = wave + 4k: tap tt = u / 2 = 2k + wave / 2 -> ky = tt >> 2 = k >> 1, kx = tt & 3 = 2 (k & 1) + wave / 2
+    const int toff0 = (wave >> 1) * ckp;
+    const int hfo0 = 16 * (wave % NFHT);
+    const bool do_bias = a.with_bias && gchunk == 0;
+    const int bcols = 16 * NFHT, bparts = 256 / bcols, bcol = tid % bcols, bpart = tid / bcols;
+    float bsum = 0.f;
+    const unsigned m_pw = magic_u32(a.PW);
+    const int total = a.PH * a.PW * 4;
+    WpRegs R;
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) wp_fetch(a, tile, tid, g0, h0, m_pw, R);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < WP_NG; ++k) {
+            const int e = 256 * k + tid;
+            if (e < total) *reinterpret_cast<f32x4*>(&patch[(e >> 2) * ckp + 4 * (e & 3)]) = ((R.gok >> k) & 1) ? R.gv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < WP_NH; ++k) {
+            const int e = 256 * k + tid;
+            *reinterpret_cast<f32x4*>(&ht[(e >> 3) * BNP + 4 * (e & 7)]) = ((R.hok >> k) & 1) ? R.hv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) wp_fetch(a, tile + gridDim.x, tid, g0, h0, m_pw, R);
+        if (do_bias && bpart < bparts) {
+#pragma unroll 4
+            for (int p = bpart; p < TH * 16; p += bparts) bsum += ht[p * BNP + bcol];
+        }
+#pragma unroll 1
+        for (int r = 0; r < TH; ++r) {
+#pragma unroll 2
+            for (int xs = 0; xs < 4; ++xs) {  // two k-steps per iteration: the second step's LDS reads are in flight behind the first's MFMAs
+                const int c = 4 * xs + g;
+                const float* ap = patch + (r * 2 * a.PW + c * 2) * ckp + i + toff0;
+                const float b = ht[(r * 16 + c) * BNP + i + hfo0];
+                float af[UW];
+#pragma unroll
+                for (int k = 0; k < UW; ++k) af[k] = ap[((k >> 1) * a.PW + 2 * (k & 1)) * ckp];
+#pragma unroll
+                for (int k = 0; k < UW; ++k) acc[k] = mfma16(af[k], b, acc[k]);
+            }
+        }
+        __syncthreads();  // every wave is done with both tiles
+    }
+    if (do_bias) {
+        smem[tid] = bpart < bparts ? bsum : 0.f;
+        __syncthreads();
+        if (tid < bcols) {
+            bsum = 0.f;
+            for (int j = 0; j < bparts; ++j) bsum += smem[tid + bcols * j];
+        }
+    }
+    const size_t pstride = (size_t)a.T * a.Cg * a.Ch + (a.with_bias ? a.Ch : 0);
+    if (do_bias && tid < 16 * NFHT) a.partial[(size_t)blockIdx.x * pstride + (size_t)a.T * a.Cg * a.Ch + h0 + tid] = bsum;
+    float* out = a.partial + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int k = 0; k < UW; ++k) {
+        const int u = wave + 4 * k, tt = u / NFHT, hf = u % NFHT;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[((size_t)tt * a.Cg + g0 + 4 * g + e) * a.Ch + h0 + 16 * hf + i] = acc[k][e];
+    }
+}
+
+// =====================================================================================================================
 // 1x1 convolutions: the weight gradient is a plain GEMM  dW[ci][co] = sum_p x[p][ci] dy[p][co]  over all P = N*H*W pixels,
 // with no spatial structure at all.  The generic kernel above still tiles it in 2-D and gives every (16 input channels,
 // 32 output channels) pair its own workgroup column, so x is re-read Ch/32 times and dy Cg/16 times.  Here a workgroup owns
@@ -725,6 +845,48 @@ static int launch_ts_t(WGradArgs& a, const TsPlan& p, hipStream_t st) {
     return MSTG_OK;
 }
 
+// the persistent kernel takes the 4x4 stride-2 family on aligned, unsliced NHWC tensors (call after plan_ts set PH for TH = 4)
+static bool wp_ok(const WGradArgs& a) {
+    const char* e = env_get(ENV_P32);
+    if (e && e[0] == '0') return false;
+    return a.Teff == 16 && a.mode == MODE_PLAIN && a.stride == 2 && a.pad == 1 && a.dil == 1 && !a.g_nchw && !a.h_nchw && !a.g_coff &&
+           !a.h_coff && a.g_ctot == a.Cg && a.h_ctot == a.Ch && a.Cg % 16 == 0 && a.Ch % (16 * WP_NFHT) == 0 && a.gH == 2 * a.hH &&
+           a.gW == 2 * a.hW && (size_t)a.gH * a.gW * a.Cg * 4 < ((size_t)1 << 32);
+}
+struct WpPlan { int S, ny; size_t lds, ws_bytes; };
+static WpPlan wp_plan(const WGradArgs& a) {  // a: after plan_ts (tiles for TH = 4)
+    WpPlan p;
+    p.ny = a.n_gchunks * (a.Ch / (16 * WP_NFHT));
+    p.lds = ((size_t)((a.PH * a.PW * a.ckp + 3) & ~3) + (size_t)WP_TH * 16 * (16 * WP_NFHT + 4)) * sizeof(float);
+    const size_t slab = ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
+    int S = 1024 / p.ny;  // at most four workgroups per CU; the launch clamps to what the kernel's registers / LDS really allow
+    while (S > 128 && (size_t)S * slab > ((size_t)48 << 20)) S >>= 1;
+    if (S < 1) S = 1;
+    if (S > a.ntiles) S = a.ntiles;
+    p.S = S;
+    p.ws_bytes = (size_t)S * slab;
+    return p;
+}
+static int launch_wp(WGradArgs& a, WpPlan& p, hipStream_t st) {
+    static int occ = 0;
+    static size_t occ_lds = 0;
+    if (!occ || occ_lds != p.lds) {
+        const void* kptr = reinterpret_cast<const void*>(&wgrad_p32_kernel);
+        if (p.lds > 64 * 1024) (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kptr, 256, p.lds) != hipSuccess || nb < 1) nb = 1;
+        occ = nb > 4 ? 4 : nb;
+        occ_lds = p.lds;
+    }
+    int S = (256 * occ) / p.ny;
+    if (S > p.S) S = p.S;
+    if (S < 1) S = 1;
+    p.S = S;
+    hipLaunchKernelGGL(wgrad_p32_kernel, dim3(S, p.ny, 1), dim3(256), p.lds, st, a);
+    MSTG_CHECK_LAUNCH("wgrad_p32_kernel");
+    return MSTG_OK;
+}
+
 static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float* dy, WGradArgs& a) {
     a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.dil = d->dil; a.T = d->KH * d->KW;
@@ -775,7 +937,9 @@ extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass
         const WGradArgs b = wgrad_1x1_block(a, wgrad_1x1_chunks(a), 0, 0);
         snprintf(name, sizeof(name), "wgrad_1x1_kernel<%d, %d>", cdiv(b.Cg, 16), cdiv(cdiv(b.Ch, 16), 4));
     } else if (use_ts) {
-        snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", plan_ts(a).UW);
+        const int uw = plan_ts(a).UW;
+        if (wp_ok(a)) snprintf(name, sizeof(name), "wgrad_p32_kernel");
+        else snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", uw);
     } else {
         const WGradPlan p = plan_wgrad(a);
         snprintf(name, sizeof(name), "wgrad_kernel<%d, %d>", p.tg, p.nfh);
@@ -788,7 +952,8 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     WGradArgs a{};
     if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
     const size_t w_old = plan_wgrad(a).ws_bytes;
-    const size_t w_ts = (a.Teff == 16 && a.mode == MODE_PLAIN) ? plan_ts(a).ws_bytes : 0;  // the only shapes the tap-split kernel takes
+    size_t w_ts = (a.Teff == 16 && a.mode == MODE_PLAIN) ? plan_ts(a).ws_bytes : 0;  // the only shapes the tap-split kernel takes
+    if (w_ts && wp_ok(a)) { const size_t w_p = wp_plan(a).ws_bytes; if (w_p > w_ts) w_ts = w_p; }
     const size_t w_11 = wgrad_1x1_ok(a) ? wgrad_1x1_workspace(a) : 0;
     size_t w = w_old > w_ts ? w_old : w_ts;
     return w > w_11 ? w : w_11;
@@ -835,10 +1000,17 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
         return MSTG_OK;
     } else if (use_ts && !(env_get(ENV_WGRAD_OLD) && env_get(ENV_WGRAD_OLD)[0] == '1')) {
         const TsPlan p = plan_ts(a);
-        if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
-        int rc = p.UW == 4 ? launch_ts_t<4>(a, p, st) : (p.UW == 8 ? launch_ts_t<8>(a, p, st) : launch_ts_t<16>(a, p, st));
-        if (rc) return rc;
-        S = p.S;
+        if (wp_ok(a)) {  // persistent, prefetching form of the same kernel
+            WpPlan q = wp_plan(a);
+            if (workspace_bytes < q.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+            if (int rc = launch_wp(a, q, st)) return rc;
+            S = q.S;
+        } else {
+            if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+            int rc = p.UW == 4 ? launch_ts_t<4>(a, p, st) : (p.UW == 8 ? launch_ts_t<8>(a, p, st) : launch_ts_t<16>(a, p, st));
+            if (rc) return rc;
+            S = p.S;
+        }
     } else {
         const WGradPlan p = plan_wgrad(a);
         if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");

@@ -25,7 +25,7 @@ def time_it(fn, reps=10):
 
 
 def run(tag_env):
-    for k in ("MSTG_P32", "MSTG_P32_TH", "MSTG_P32_WLDS"):
+    for k in ("MSTG_P32", "MSTG_P32_TH", "MSTG_P32_WLDS", "MSTG_P32_DBG"):
         os.environ.pop(k, None)
     for kv in tag_env.split():
         k, v = kv.split("=")
@@ -43,11 +43,14 @@ def run(tag_env):
         d = ops.make_desc(N, H, W, Ci, Ho, Wo, Co, 4, 2, 1, 1, transposed=tr)
         tf = time_it(lambda: ops.conv_fwd_raw(d, x, w, b, y))
         tb = time_it(lambda: ops.conv_dgrad_raw(d, dy, w, dx))
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        tw = time_it(lambda: ops.conv_wgrad_raw(d, x, dy, dw, None if tr else db))
         fl = 2.0 * N * (Ho * Wo if not tr else H * W * 4) * Co * Ci * (16 if not tr else 4)
-        out.append(f"{tag:14s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)")
+        names = " / ".join(ops._kernel_name(d, k).replace("conv_p32_kernel", "p32").replace("igemm_light_kernel", "light") for k in (0, 1))
+        out.append(f"{tag:14s} {names:46s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)  wgrad {tw:.3f} ms ({fl / tw / 1e9:5.1f} TF)")
     print(f"--- {tag_env or 'default'}")
     print("\n".join(out), flush=True)
 
 
-for env in sys.argv[1:] or ["MSTG_P32=0", "", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=0 MSTG_P32_TH=8"]:
+for env in sys.argv[1:] or ["MSTG_P32=0", ""]:
     run(env)
