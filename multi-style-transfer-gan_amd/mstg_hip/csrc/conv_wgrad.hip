@@ -542,6 +542,217 @@ __global__ __launch_bounds__(256, 3) void wgrad_p32_kernel(const WGradArgs a) {
 }
 
 // =====================================================================================================================
+// Persistent form of the pixel-split kernel for the two 7x7 layers with a 3-channel side (stem: the RGB image is the gathered
+// tensor, MODE_PACKX; head: the RGB gradient is the grid tensor, MODE_DPACK), 16 channels on the other side: the next tile's
+// patch and grid tile travel into registers behind the current tile's 112 MFMAs per wave, and the k-loop keeps the next step's
+// LDS reads in flight behind the current step's MFMAs.  LDS layouts, tap packing, slab layout and reduce kernel are those of
+// wgrad_kernel<14, 1>.
+// =====================================================================================================================
+template <int MODE>
+struct W7 {
+    static constexpr int NBIG = MODE == MODE_PACKX ? 2 : 6;  // 16-byte NHWC quads per thread: 128 x 4 tile quads / 322 x 4 patch quads
+    static constexpr int NSM = MODE == MODE_PACKX ? 2 : 1;   // NCHW pixels (3 planes each) per thread: 322 patch / 160 tile pixels
+    static constexpr int PH = 14, PW = 23, HTW = 20, TG = 14;
+};
+
+template <int MODE>
+struct W7Regs {
+    f32x4 big[W7<MODE>::NBIG];
+    float sm[W7<MODE>::NSM][3];
+    unsigned okb, oks;
+};
+
+template <int MODE>
+__device__ __forceinline__ void w7_fetch(const WGradArgs& a, int tile, int tid, W7Regs<MODE>& R) {
+    typedef W7<MODE> K;
+    const int tx0 = tile % a.tiles_x, ty0 = (tile / a.tiles_x) % a.tiles_y, n = tile / (a.tiles_x * a.tiles_y);
+    const int gx0 = tx0 * WT_W - a.xshift;
+    const int y0 = ty0 * WT_H - 3, x0 = gx0 - 3;
+    R.okb = R.oks = 0;
+    if (MODE == MODE_PACKX) {
+        const float* himg = a.h + (size_t)n * a.hH * a.hW * 16;
+#pragma unroll
+        for (int k = 0; k < K::NBIG; ++k) {
+            const int e = 256 * k + tid, pix = e >> 2;
+            const int gy = ty0 * WT_H + (pix >> 4), gx = gx0 + (pix & 15);
+            const bool ok = gy < a.hH && gx < a.hW;
+            R.okb |= (unsigned)ok << k;
+            R.big[k] = *reinterpret_cast<const f32x4*>(himg + (ok ? (unsigned)((gy * a.hW + gx) * 16 + 4 * (e & 3)) : 0u));
+        }
+        const size_t plane = (size_t)a.gH * a.gW;
+        const float* gimg = a.g + ((size_t)n * a.g_ctot + a.g_coff) * plane;
+#pragma unroll
+        for (int k = 0; k < K::NSM; ++k) {
+            const int e = 256 * k + tid;
+            const int r = e / K::PW, c = e - r * K::PW;
+            const bool ok = e < K::PH * K::PW && (unsigned)(y0 + r) < (unsigned)a.gH && (unsigned)(x0 + c) < (unsigned)a.gW;
+            R.oks |= (unsigned)ok << k;
+            const unsigned off = ok ? (unsigned)((y0 + r) * a.gW + x0 + c) : 0u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) R.sm[k][ch] = gimg[off + (ch < a.Cg ? ch * plane : 0)];
+        }
+    } else {
+        const float* gimg = a.g + (size_t)n * a.gH * a.gW * 16;
+#pragma unroll
+        for (int k = 0; k < K::NBIG; ++k) {
+            const int e = 256 * k + tid, pix = e >> 2;
+            const int r = pix / K::PW, c = pix - r * K::PW;
+            const bool ok = e < K::PH * K::PW * 4 && (unsigned)(y0 + r) < (unsigned)a.gH && (unsigned)(x0 + c) < (unsigned)a.gW;
+            R.okb |= (unsigned)ok << k;
+            R.big[k] = *reinterpret_cast<const f32x4*>(gimg + (ok ? (unsigned)(((y0 + r) * a.gW + x0 + c) * 16 + 4 * (e & 3)) : 0u));
+        }
+        const size_t plane = (size_t)a.hH * a.hW;
+        const float* himg = a.h + ((size_t)n * a.h_ctot + a.h_coff) * plane;
+        {
+            const int e = tid;
+            const int r = e / K::HTW, c = e - r * K::HTW;
+            const int gy = ty0 * WT_H + r, gx = gx0 + c;
+            const bool ok = e < WT_H * K::HTW && gy < a.hH && (unsigned)gx < (unsigned)a.hW;
+            R.oks = (unsigned)ok;
+            const unsigned off = ok ? (unsigned)(gy * a.hW + gx) : 0u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) R.sm[0][ch] = himg[off + (ch < a.Ch ? ch * plane : 0)];
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void w7_commit(const WGradArgs& a, int tid, const W7Regs<MODE>& R, float* patch, float* ht) {
+    typedef W7<MODE> K;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == MODE_PACKX) {
+#pragma unroll
+        for (int k = 0; k < K::NBIG; ++k) {
+            const int e = 256 * k + tid;
+            *reinterpret_cast<f32x4*>(&ht[(e >> 2) * 20 + 4 * (e & 3)]) = ((R.okb >> k) & 1) ? R.big[k] : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < K::NSM; ++k) {
+            const int e = 256 * k + tid;
+            if (e < K::PH * K::PW) {
+                f32x4 w = zero;
+                if ((R.oks >> k) & 1) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) w[ch] = ch < a.Cg ? R.sm[k][ch] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(&patch[e * 4]) = w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < K::NBIG; ++k) {
+            const int e = 256 * k + tid;
+            if (e < K::PH * K::PW * 4) *reinterpret_cast<f32x4*>(&patch[(e >> 2) * 20 + 4 * (e & 3)]) = ((R.okb >> k) & 1) ? R.big[k] : zero;
+        }
+        if (tid < WT_H * K::HTW) {
+            f32x4 w = zero;
+            if (R.oks & 1) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) w[ch] = ch < a.Ch ? R.sm[0][ch] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&ht[tid * 4]) = w;
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void wgrad7_kernel(const WGradArgs a) {
+    typedef W7<MODE> K;
+    constexpr int TG = K::TG, BNP = 20;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int ckp = MODE == MODE_PACKX ? 4 : 20;
+    float* patch = smem;                                          // [14][23][ckp]
+    float* ht = smem + ((K::PH * K::PW * ckp + 3) & ~3);          // packx: [128][20]; dpack: [8][20][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+    f32x4 acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // packed tap t = (ky = t / 2, four columns from 4 (t % 2)); dpack reads them three pixels to the right (the tile's shift)
+    constexpr int kx_shift = MODE == MODE_DPACK ? 3 : 0;
+    const bool do_bias = a.with_bias;
+    constexpr int bcols = MODE == MODE_DPACK ? 4 : 16, bparts = 256 / bcols;
+    const int bcol = tid % bcols, bpart = tid / bcols;
+    float bsum = 0.f;
+    constexpr int hrow = MODE == MODE_DPACK ? K::HTW * 4 : 16 * BNP, hcol = MODE == MODE_DPACK ? 4 : BNP;
+    W7Regs<MODE> R;
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) w7_fetch<MODE>(a, tile, tid, R);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        w7_commit<MODE>(a, tid, R, patch, ht);
+        __syncthreads();
+        if (tile + (int)gridDim.x < a.ntiles) w7_fetch<MODE>(a, tile + gridDim.x, tid, R);
+        if (do_bias) {
+            if (MODE != MODE_DPACK) {
+#pragma unroll 4
+                for (int p = bpart; p < 128; p += bparts) bsum += ht[p * BNP + bcol];
+            } else {
+#pragma unroll
+                for (int p = bpart; p < 128; p += 64) bsum += ht[((p >> 4) * K::HTW + (p & 15) + 3) * 4 + bcol];
+            }
+        }
+        // this wave's two tile rows, 4 pixels per k-step; two steps per trip: the second step's LDS reads fly behind the first's MFMAs
+#pragma unroll 2
+        for (int st = 0; st < 8; ++st) {
+            const int r = 2 * wave + (st >> 2), c = 4 * (st & 3) + g;
+            const float bf = ht[r * hrow + c * hcol + i];
+            const float* ap = patch + (r * K::PW + c + kx_shift) * ckp + i;
+            float af[TG];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) af[t] = ap[((t >> 1) * K::PW + 4 * (t & 1)) * ckp];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t] = mfma16(af[t], bf, acc[t]);
+        }
+        __syncthreads();
+    }
+    // ---- sum the four waves through LDS (fixed order), then write this workgroup's partial ------------------------------------
+    if (do_bias) {  // uniform
+        smem[tid] = bsum;
+        __syncthreads();
+        if (tid < bcols) {
+            bsum = 0.f;
+            for (int j = 0; j < bparts; ++j) bsum += smem[tid + bcols * j];
+        }
+        __syncthreads();
+    }
+    float* red = smem;  // [TG][256]
+    for (int wv = 1; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) *reinterpret_cast<f32x4*>(&red[(t * 64 + lane) * 4]) = acc[t];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) acc[t] += *reinterpret_cast<const f32x4*>(&red[(t * 64 + lane) * 4]);
+        }
+        __syncthreads();
+    }
+    const size_t pstride = (size_t)a.T * a.Cg * a.Ch + (a.with_bias ? a.Ch : 0);
+    if (do_bias && tid < bcols && tid < a.Ch) a.partial[(size_t)blockIdx.x * pstride + (size_t)a.T * a.Cg * a.Ch + tid] = bsum;
+    if (wave == 0) {
+        float* out = a.partial + (size_t)blockIdx.x * pstride;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int tap, gch, hch;
+                bool ok;
+                if (MODE == MODE_PACKX) {  // row m = 4 * kx_low + c
+                    const int kx = 4 * (t & 1) + g;
+                    tap = (t >> 1) * 7 + kx; gch = e; hch = i;
+                    ok = kx < 7 && gch < a.Cg;
+                } else {                   // column n = 4 * delta + co ; tap kx = 4 j + 3 - delta
+                    const int kx = 4 * (t & 1) + 3 - (i >> 2);
+                    tap = (t >> 1) * 7 + kx; gch = 4 * g + e; hch = i & 3;
+                    ok = kx >= 0 && kx < 7 && hch < a.Ch;
+                }
+                if (ok) out[((size_t)tap * a.Cg + gch) * a.Ch + hch] = acc[t][e];
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
 // 1x1 convolutions: the weight gradient is a plain GEMM  dW[ci][co] = sum_p x[p][ci] dy[p][co]  over all P = N*H*W pixels,
 // with no spatial structure at all.  The generic kernel above still tiles it in 2-D and gives every (16 input channels,
 // 32 output channels) pair its own workgroup column, so x is re-read Ch/32 times and dy Cg/16 times.  Here a workgroup owns
@@ -887,6 +1098,30 @@ static int launch_wp(WGradArgs& a, WpPlan& p, hipStream_t st) {
     return MSTG_OK;
 }
 
+// the two 7x7 layers with a 3-channel side (see wgrad7_kernel); everything else about them is fixed by the module
+static bool w7_ok(const WGradArgs& a) {
+    const char* e = env_get(ENV_P32);
+    if (e && e[0] == '0') return false;
+    if (a.KH != 7 || a.KW != 7 || a.stride != 1 || a.pad != 3 || a.dil != 1 || a.gH != a.hH || a.gW != a.hW) return false;
+    if ((size_t)a.hH * a.hW * 16 >= ((size_t)1 << 30)) return false;
+    if (a.mode == MODE_PACKX) return a.g_nchw && a.Cg <= 3 && !a.h_nchw && a.Ch == 16 && a.h_ctot == 16 && a.h_coff == 0;
+    if (a.mode == MODE_DPACK) return a.h_nchw && a.Ch <= 3 && !a.g_nchw && a.Cg == 16 && a.g_ctot == 16 && a.g_coff == 0;
+    return false;
+}
+static size_t w7_lds(const WGradArgs& a) {
+    const size_t stage = ((size_t)((14 * 23 * (a.mode == MODE_PACKX ? 4 : 20) + 3) & ~3) + (a.mode == MODE_PACKX ? 128 * 20 : 8 * 20 * 4)) * sizeof(float);
+    const size_t red = (size_t)14 * 256 * sizeof(float);
+    return stage > red ? stage : red;
+}
+static int w7_splits(const WGradArgs& a) { return a.ntiles < 768 ? a.ntiles : 768; }
+static int launch_w7(WGradArgs& a, int S, hipStream_t st) {
+    const size_t lds = w7_lds(a);
+    if (a.mode == MODE_PACKX) hipLaunchKernelGGL((wgrad7_kernel<MODE_PACKX>), dim3(S), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((wgrad7_kernel<MODE_DPACK>), dim3(S), dim3(256), lds, st, a);
+    MSTG_CHECK_LAUNCH("wgrad7_kernel");
+    return MSTG_OK;
+}
+
 static int fill_wgrad_args(const mstg_conv_desc* d, const float* x, const float* dy, WGradArgs& a) {
     a.N = d->N;
     a.KH = d->KH; a.KW = d->KW; a.dil = d->dil; a.T = d->KH * d->KW;
@@ -940,6 +1175,8 @@ extern "C" const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass
         const int uw = plan_ts(a).UW;
         if (wp_ok(a)) snprintf(name, sizeof(name), "wgrad_p32_kernel");
         else snprintf(name, sizeof(name), "wgrad_ts_kernel<%d>", uw);
+    } else if (w7_ok(a)) {
+        snprintf(name, sizeof(name), "wgrad7_kernel<%d>", a.mode);
     } else {
         const WGradPlan p = plan_wgrad(a);
         snprintf(name, sizeof(name), "wgrad_kernel<%d, %d>", p.tg, p.nfh);
@@ -956,6 +1193,7 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     if (w_ts && wp_ok(a)) { const size_t w_p = wp_plan(a).ws_bytes; if (w_p > w_ts) w_ts = w_p; }
     const size_t w_11 = wgrad_1x1_ok(a) ? wgrad_1x1_workspace(a) : 0;
     size_t w = w_old > w_ts ? w_old : w_ts;
+    if (w7_ok(a)) { const size_t w_7 = (size_t)w7_splits(a) * ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float); if (w_7 > w) w = w_7; }
     return w > w_11 ? w : w_11;
 }
 
@@ -1011,6 +1249,10 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
             if (rc) return rc;
             S = p.S;
         }
+    } else if (w7_ok(a)) {
+        S = w7_splits(a);
+        if (workspace_bytes < (size_t)S * ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float)) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
+        if (int rc = launch_w7(a, S, st)) return rc;
     } else {
         const WGradPlan p = plan_wgrad(a);
         if (workspace_bytes < p.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");

@@ -87,6 +87,12 @@ CONV_CASES = [
     ("p32 convT 16->16 17x33 N3", 3, 17, 33, 16, 16, 4, 2, 1, 1, 1, 0, 0, 0),
     ("p32 convT 32->32 64x64", 1, 64, 64, 32, 32, 4, 2, 1, 1, 1, 0, 0, 0),
     ("p32 convT 64->16 1x1", 2, 1, 1, 64, 16, 4, 2, 1, 1, 1, 0, 0, 0),
+    # the persistent 7x7 weight-gradient kernel (wgrad7_kernel): ragged tiles, several images, more tiles than workgroups
+    ("w7 stem7x7 3->16 nchw-in ragged 37x53 N3", 3, 37, 53, 3, 16, 7, 1, 3, 1, 0, 1, 0, 0),
+    ("w7 head7x7 16->3 nchw-out ragged 37x53 N3", 3, 37, 53, 16, 3, 7, 1, 3, 1, 0, 0, 1, 0),
+    ("w7 stem7x7 3->16 nchw-in 256x256 N4", 4, 256, 256, 3, 16, 7, 1, 3, 1, 0, 1, 0, 0),
+    ("w7 head7x7 16->3 nchw-out tanh 256x256 N4", 4, 256, 256, 16, 3, 7, 1, 3, 1, 0, 0, 1, 3),
+    ("w7 stem7x7 1->16 nchw-in 16x16", 2, 16, 16, 1, 16, 7, 1, 3, 1, 0, 1, 0, 0),
 ]
 
 
@@ -226,7 +232,7 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     test_conv_channel_slices_and_accumulate(1, 32, 32, 32)
     for case in CONV_CASES:
         if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4") or (k.startswith("MSTG_P32") and (
-                case[0].startswith("p32") or case[0].startswith("convT") or case[0].startswith("k4s2"))):
+                case[0].startswith(("p32", "convT", "k4s2", "w7", "stem7x7", "head7x7")))):
             test_conv_fwd_bwd(case)
     if k == "MSTG_ATTN_BLK64":
         test_window_attention_core(2, 8, 8, 64)

@@ -48,6 +48,20 @@ def run(tag_env):
         fl = 2.0 * N * (Ho * Wo if not tr else H * W * 4) * Co * Ci * (16 if not tr else 4)
         names = " / ".join(ops._kernel_name(d, k).replace("conv_p32_kernel", "p32").replace("igemm_light_kernel", "light") for k in (0, 1))
         out.append(f"{tag:14s} {names:46s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)  wgrad {tw:.3f} ms ({fl / tw / 1e9:5.1f} TF)")
+    for tag, N, H, Ci, Co, xn, yn in (("stem 3->16 k7", 64, 256, 3, 16, 1, 0), ("head 16->3 k7", 64, 256, 16, 3, 0, 1)):
+        x = torch.randn((N, Ci, H, H) if xn else (N, H, H, Ci), device=dev)
+        w = torch.randn(Co, Ci, 7, 7, device=dev) * 0.05
+        b = torch.randn(Co, device=dev)
+        y = torch.empty((N, Co, H, H) if yn else (N, H, H, Co), device=dev)
+        dy = torch.randn_like(y)
+        dx = torch.empty_like(x)
+        d = ops.make_desc(N, H, H, Ci, H, H, Co, 7, 1, 3, 1, x_nchw=xn, y_nchw=yn)
+        tf = time_it(lambda: ops.conv_fwd_raw(d, x, w, b, y))
+        tb = time_it(lambda: ops.conv_dgrad_raw(d, dy, w, dx))
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        tw = time_it(lambda: ops.conv_wgrad_raw(d, x, dy, dw, db))
+        fl = 2.0 * N * H * H * Co * Ci * 49
+        out.append(f"{tag:14s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)  wgrad {tw:.3f} ms ({fl / tw / 1e9:5.1f} TF)")
     print(f"--- {tag_env or 'default'}")
     print("\n".join(out), flush=True)
 
