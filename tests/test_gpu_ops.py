@@ -145,6 +145,7 @@ def test_conv_stream_kernel(case, monkeypatch):
     checks as the default kernels: interior fast path, border tiles, dpack exchange, channel chunks, parity classes."""
     from mstg_hip import _lib
     monkeypatch.setenv("MSTG_STREAM", "1f")
+    monkeypatch.setenv("MSTG_P32", "0")  # the persistent 4x4 stride-2 kernel (conv_p32.hip) otherwise takes two of these shapes
     from mstg_hip import ops as _ops
     _ops.refresh_env()
     name, N, H, W, Cin, Cout, k, s, p, d, tr, x_nchw, y_nchw, act = case
