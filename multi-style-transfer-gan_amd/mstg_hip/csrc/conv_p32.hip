@@ -36,7 +36,7 @@ struct P32Plan {
     unsigned koff[P32_MAX_STEPS];                          // byte offset of the step's tap / channel chunk from the lane's pixel base
     int8_t tky[P32_MAX_STEPS], tkx[P32_MAX_STEPS];         // filter tap of the step
     int16_t tcb[P32_MAX_STEPS];                            // first source channel of the step
-    int PH, PW, pixstride, oy0, ox0, stride, up, NF, TH, npf, wlds;
+    int PH, PW, pixstride, oy0, ox0, stride, up, NF, TH, npf, wlds, KW;
     unsigned m_pw, m_ntile, m_tx;
 };
 
@@ -56,7 +56,7 @@ __global__ void p32_pack_kernel(const P32Plan p, const float* __restrict__ w, co
         const int j = e & 3, lane = (e >> 2) & 63, sf = e >> 8, f = sf % p.NF, s = sf / p.NF;
         const int co = 16 * f + (lane & 15), ci = p.tcb[s] + 4 * (lane >> 4) + j;
         float v = 0.f;
-        if (co < Cout && ci < Cin) v = w[(size_t)co * w_so + (size_t)ci * w_sr + p.tky[s] * 4 + p.tkx[s]];
+        if (co < Cout && ci < Cin) v = w[(size_t)co * w_so + (size_t)ci * w_sr + p.tky[s] * p.KW + p.tkx[s]];
         wpk[e] = v;
     }
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 16 * p.NF; c += gridDim.x * blockDim.x) bpk[c] = (bias && c < Cout) ? bias[c] : 0.f;
@@ -246,8 +246,13 @@ bool p32_eligible(const IGemmArgs& a) {
     auto ch_ok = [](int c) { return c == 16 || c == 32 || c == 64; };
     if (a.x_nchw || a.y_nchw || a.x_coff || a.y_coff || a.x_ctot != a.Cr || a.y_ctot != a.Co) return false;
     if (!ch_ok(a.Cr) || !ch_ok(a.Co)) return false;
-    if (a.KH != 4 || a.KW != 4 || a.dil != 1 || a.flip || a.accumulate || a.act != MSTG_ACT_NONE) return false;
-    if (a.phase ? !(a.Ho == 2 * a.H && a.Wo == 2 * a.W) : !(a.stride == 2 && a.pad == 1 && a.H == 2 * a.Ho && a.W == 2 * a.Wo)) return false;
+    if (a.accumulate || a.act != MSTG_ACT_NONE) return false;
+    if (a.KH == 1 && a.KW == 1) {  // 1x1: a streaming GEMM over the pixels (forward and, through swapped strides, the input gradient)
+        if (a.phase || a.stride != 1 || a.pad != 0 || a.H != a.Ho || a.W != a.Wo) return false;
+    } else {
+        if (a.KH != 4 || a.KW != 4 || a.dil != 1 || a.flip) return false;
+        if (a.phase ? !(a.Ho == 2 * a.H && a.Wo == 2 * a.W) : !(a.stride == 2 && a.pad == 1 && a.H == 2 * a.Ho && a.W == 2 * a.Wo)) return false;
+    }
     P32Plan p;
     return p32_plan(a, p) == MSTG_OK;  // e.g. a 64-channel stride-2 patch does not fit the prefetch registers: igemm_light takes it
 }
@@ -256,15 +261,22 @@ static int p32_plan(const IGemmArgs& a, P32Plan& p) {
     memset(&p, 0, sizeof(p));
     const int Cin = a.Cr, nchunk = Cin / 16;
     p.NF = a.Co / 16;
+    const bool one = a.KH == 1;
+    p.KW = a.KW;
     p.up = a.phase ? 1 : 0;
-    p.stride = p.up ? 1 : 2;
-    p.pixstride = 4 * Cin + (p.up ? 32 : 16);
-    const int halo_lo = -1, halo_hi = p.up ? 1 : 2;  // gather rows y*s - 1 ... y*s + 2 (stride 2) / y - 1 ... y + 1 (classes)
+    p.stride = (p.up || one) ? 1 : 2;
+    p.pixstride = 4 * Cin + (p.stride == 1 ? 32 : 16);
+    const int halo_lo = one ? 0 : -1, halo_hi = one ? 0 : (p.up ? 1 : 2);  // gather rows y*s - 1 ... y*s + 2 (stride 2) / y - 1 ... y + 1 (classes)
     const int ext = halo_hi - halo_lo;
     p.PW = (P32_TW - 1) * p.stride + 1 + ext;
     p.oy0 = p.ox0 = halo_lo;
     int s = 0;
-    if (!p.up) {
+    if (one) {
+        p.nseg = 1;
+        p.seg[0].s0 = 0;
+        for (int c = 0; c < nchunk; ++c, ++s) { p.koff[s] = (unsigned)(64 * c); p.tky[s] = p.tkx[s] = 0; p.tcb[s] = (int16_t)(16 * c); }
+        p.seg[0].s1 = s;
+    } else if (!p.up) {
         p.nseg = 1;
         p.seg[0].s0 = 0;
         for (int ky = 0; ky < 4; ++ky)

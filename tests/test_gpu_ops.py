@@ -87,6 +87,10 @@ CONV_CASES = [
     ("p32 convT 16->16 17x33 N3", 3, 17, 33, 16, 16, 4, 2, 1, 1, 1, 0, 0, 0),
     ("p32 convT 32->32 64x64", 1, 64, 64, 32, 32, 4, 2, 1, 1, 1, 0, 0, 0),
     ("p32 convT 64->16 1x1", 2, 1, 1, 64, 16, 4, 2, 1, 1, 1, 0, 0, 0),
+    ("p32 1x1 32->32 ragged 37x53 N3", 3, 37, 53, 32, 32, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("p32 1x1 64->64 24x40", 2, 24, 40, 64, 64, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("p32 1x1 32->64 128x128", 1, 128, 128, 32, 64, 1, 1, 0, 1, 0, 0, 0, 0),
+    ("p32 1x1 64->16 5x7", 2, 5, 7, 64, 16, 1, 1, 0, 1, 0, 0, 0, 0),
     # the persistent 7x7 weight-gradient kernel (wgrad7_kernel): ragged tiles, several images, more tiles than workgroups
     ("w7 stem7x7 3->16 nchw-in ragged 37x53 N3", 3, 37, 53, 3, 16, 7, 1, 3, 1, 0, 1, 0, 0),
     ("w7 head7x7 16->3 nchw-out ragged 37x53 N3", 3, 37, 53, 16, 3, 7, 1, 3, 1, 0, 0, 1, 0),

@@ -48,6 +48,16 @@ def run(tag_env):
         fl = 2.0 * N * (Ho * Wo if not tr else H * W * 4) * Co * Ci * (16 if not tr else 4)
         names = " / ".join(ops._kernel_name(d, k).replace("conv_p32_kernel", "p32").replace("igemm_light_kernel", "light") for k in (0, 1))
         out.append(f"{tag:14s} {names:46s} fwd {tf:.3f} ms ({fl / tf / 1e9:5.1f} TF)  dgrad {tb:.3f} ms ({fl / tb / 1e9:5.1f} TF)  wgrad {tw:.3f} ms ({fl / tw / 1e9:5.1f} TF)")
+    for tag, N, H, Ci in (("1x1 16->16", 64, 256, 16), ("1x1 32->32", 64, 128, 32), ("1x1 64->64", 64, 64, 64)):
+        x = torch.randn(N, H, H, Ci, device=dev)
+        w = torch.randn(Ci, Ci, 1, 1, device=dev) * 0.1
+        b = torch.randn(Ci, device=dev)
+        y = torch.empty_like(x)
+        d = ops.make_desc(N, H, H, Ci, H, H, Ci, 1, 1, 0, 1)
+        tf = time_it(lambda: ops.conv_fwd_raw(d, x, w, b, y))
+        tb = time_it(lambda: ops.conv_dgrad_raw(d, y, w, x))
+        gb = 2 * x.numel() * 4 / 1e9
+        out.append(f"{tag:14s} fwd {tf:.3f} ms ({gb / tf * 1e3:5.0f} GB/s)  dgrad {tb:.3f} ms ({gb / tb * 1e3:5.0f} GB/s)")
     for tag, N, H, Ci, Co, xn, yn in (("stem 3->16 k7", 64, 256, 3, 16, 1, 0), ("head 16->3 k7", 64, 256, 16, 3, 0, 1)):
         x = torch.randn((N, Ci, H, H) if xn else (N, H, H, Ci), device=dev)
         w = torch.randn(Co, Ci, 7, 7, device=dev) * 0.05
