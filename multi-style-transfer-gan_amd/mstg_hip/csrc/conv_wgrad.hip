@@ -787,32 +787,44 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     const unsigned m_qa = magic_u32(qa), m_qb = magic_u32(qb);
     float bsum = 0.f;
     const long ntiles = (P + P1 - 1) / P1;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Both tiles of the NEXT pixel run travel into registers behind the current run's MFMAs (ea + eb <= 2048 float4 elements:
+    // wgrad_1x1_tile): element e of a thread is row pr, channel quad q of the x tile (e < ea) or of the dy tile.
+    f32x4 v[8];
+    unsigned okm = 0;
+    auto locate = [&](int e, bool& isa, int& pr, int& q) {
+        isa = e < ea;
+        const int eb_ = e - ea;
+        pr = isa ? (qa == 1 ? e : (int)__umulhi((unsigned)e, m_qa)) : (qb == 1 ? eb_ : (int)__umulhi((unsigned)(eb_ < 0 ? 0 : eb_), m_qb));
+        q = isa ? e - pr * qa : eb_ - pr * qb;
+    };
+    auto fetch = [&](long tile) {
         const long p0 = tile * P1;
-        __syncthreads();
-        // ---- stage both tiles: up to 8 + 8 independent 16-byte loads per thread, rows beyond P zero ---------------------------
-        for (int e0 = 0; e0 < ea + eb; e0 += 2048) {
-            f32x4 v[8];
-            int dst[8];
+        okm = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = e0 + 256 * k + tid;
-                const bool isa = e < ea;
-                const int eb_ = e - ea;
-                const int pr = isa ? (qa == 1 ? e : (int)__umulhi((unsigned)e, m_qa)) : (qb == 1 ? eb_ : (int)__umulhi((unsigned)(eb_ < 0 ? 0 : eb_), m_qb));
-                const int q = isa ? e - pr * qa : eb_ - pr * qb;
-                const bool ok = e < ea + eb && p0 + pr < P;
-                const float* src = isa ? x + (size_t)(p0 + (ok ? pr : 0)) * g_ctot + g_coff + 4 * q
-                                       : dy + (size_t)(p0 + (ok ? pr : 0)) * h_ctot + h_coff + 4 * (ok ? q : 0);
-                v[k] = *reinterpret_cast<const f32x4*>(e < ea + eb ? src : x);
-                if (!ok) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                dst[k] = e >= ea + eb ? -1 : (isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q);
+        for (int k = 0; k < 8; ++k) {
+            const int e = 256 * k + tid;
+            bool isa; int pr, q;
+            locate(e, isa, pr, q);
+            const bool ok = e < ea + eb && p0 + pr < P;
+            okm |= (unsigned)ok << k;
+            const float* src = isa ? x + (size_t)(p0 + (ok ? pr : 0)) * g_ctot + g_coff + 4 * q
+                                   : dy + (size_t)(p0 + (ok ? pr : 0)) * h_ctot + h_coff + 4 * (ok ? q : 0);
+            v[k] = *reinterpret_cast<const f32x4*>(e < ea + eb ? src : x);
+        }
+    };
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = 256 * k + tid;
+            if (e < ea + eb) {
+                bool isa; int pr, q;
+                locate(e, isa, pr, q);
+                *reinterpret_cast<f32x4*>(&smem[isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q]) = ((okm >> k) & 1) ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (dst[k] >= 0) *reinterpret_cast<f32x4*>(&smem[dst[k]]) = v[k];
         }
         __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         if (with_bias && tid < Ch) {
 #pragma unroll 8
             for (int p = 0; p < P1; ++p) bsum += Bs[p * ldb + tid];
@@ -833,6 +845,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
 #pragma unroll
                 for (int k = 0; k < NW; ++k) acc[mf][k] = mfma16(af[mf], bf[k], acc[mf][k]);
         }
+        __syncthreads();  // every wave is done with both tiles
     }
     if (KS > 1) {  // sum the k-parts of a fragment through LDS in a fixed order (NW == 1 here)
         __syncthreads();

@@ -56,8 +56,11 @@ def run(tag_env):
         d = ops.make_desc(N, H, H, Ci, H, H, Ci, 1, 1, 0, 1)
         tf = time_it(lambda: ops.conv_fwd_raw(d, x, w, b, y))
         tb = time_it(lambda: ops.conv_dgrad_raw(d, y, w, x))
+        dw, db = torch.empty_like(w), torch.empty_like(b)
+        xx, yy = torch.randn_like(x), torch.randn_like(x)
+        tw = time_it(lambda: ops.conv_wgrad_raw(d, xx, yy, dw, db))
         gb = 2 * x.numel() * 4 / 1e9
-        out.append(f"{tag:14s} fwd {tf:.3f} ms ({gb / tf * 1e3:5.0f} GB/s)  dgrad {tb:.3f} ms ({gb / tb * 1e3:5.0f} GB/s)")
+        out.append(f"{tag:14s} fwd {tf:.3f} ms ({gb / tf * 1e3:5.0f} GB/s)  dgrad {tb:.3f} ms ({gb / tb * 1e3:5.0f} GB/s)  wgrad {tw:.3f} ms ({gb / tw * 1e3:5.0f} GB/s)")
     for tag, N, H, Ci, Co, xn, yn in (("stem 3->16 k7", 64, 256, 3, 16, 1, 0), ("head 16->3 k7", 64, 256, 16, 3, 0, 1)):
         x = torch.randn((N, Ci, H, H) if xn else (N, H, H, Ci), device=dev)
         w = torch.randn(Co, Ci, 7, 7, device=dev) * 0.05
