@@ -68,6 +68,16 @@ size_t mstg_conv2d_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias /*nullable*/,
                     float* y, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = d(loss)/d(module input), from dy = d(loss)/d(module output) */
+/* Forward with InstanceNorm folded in on either side, for the layers the persistent kernel covers (4x4 stride-2 Conv2d /
+ * ConvTranspose2d and 1x1 Conv2d at 16 / 32 / 64 channels, unsliced NHWC, no fused activation): in_stats (nullable) = (mean, rstd)
+ * [N][Cin][2] of the RAW source -- it is normalised and ReLU'd while staged, i.e. x is what stands in front of
+ * nn.InstanceNorm2d + nn.ReLU (enhanced_generator.py:54-75) and the normalised tensor is never written; out_stats (nullable) =
+ * (mean, rstd) [N][Cout][2] of y, summed in the epilogue (same layout as mstg_norm_stats; sums of squares instead of pivoted
+ * sums, combined in double).  Backward: mstg_conv2d_dgrad / _wgrad as for mstg_conv2d_fwd. */
+int mstg_conv2d_fwd_norm_supported(const mstg_conv_desc* d);
+size_t mstg_conv2d_fwd_norm_workspace_bytes(const mstg_conv_desc* d);
+int mstg_conv2d_fwd_norm(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias, float* y,
+                         float* out_stats, void* workspace, size_t workspace_bytes, void* stream);
 int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
                       size_t workspace_bytes, void* stream);
 /* dw (same layout as w) and dbias (nullable) ; workspace holds per-split partial sums (deterministic, no atomics);

@@ -87,12 +87,22 @@ class _Stage(nn.Sequential):
     """conv(T) -> IN -> ReLU -> LocalAttention -> MultiScaleBlock with the reference's child indices 0..4."""
 
     def forward_nhwc(self, x):
-        x = self[0](x, nhwc=True)
-        att = self[3]
-        if (att.window_size == 4 and ops.fused_attention_supported(x.shape[3]) and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0
-                and os.environ.get("MSTG_ATTN_UNFUSED") != "1" and os.environ.get("MSTG_NORM_ATTN", "1") != "0"):
+        conv, att = self[0], self[3]
+        transposed = isinstance(conv, nn.ConvTranspose2d)
+        cout = conv.out_channels
+        fold = (att.window_size == 4 and ops.fused_attention_supported(cout) and os.environ.get("MSTG_ATTN_UNFUSED") != "1"
+                and os.environ.get("MSTG_NORM_ATTN", "1") != "0")
+        stats = None
+        if (fold and os.environ.get("MSTG_NORM_EPILOGUE", "1") != "0" and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
+                and conv.padding == (1, 1) and ops.conv_norm_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, 4, 2, 1, 1,
+                                                                      transposed)):
+            # the norm's statistics come out of the convolution's epilogue: no pass over the tensor for them
+            x, stats = ops.conv2d_stats(x, conv.weight, conv.bias, 4, 2, 1, 1, transposed=transposed)
+        else:
+            x = conv(x, nhwc=True)
+        if fold and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0:
             # IN + ReLU folded into the attention kernels (its only consumer): the normalised tensor is never written
-            x = ops.NormLocalAttentionFn.apply(x, att.qkv.weight, att.qkv.bias, att.proj.weight, att.proj.bias)
+            x = ops.NormLocalAttentionFn.apply(x, att.qkv.weight, att.qkv.bias, att.proj.weight, att.proj.bias, stats)
         else:
             x = ops.instnorm_act(x, ACT_RELU)
             x = att.forward_nhwc(x)

@@ -1161,6 +1161,32 @@ extern "C" int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const fl
     return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- forward with InstanceNorm folded in on either side (only where the persistent kernel runs: conv_p32.hip) ----------------------
+extern "C" int mstg_conv2d_fwd_norm_supported(const mstg_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    IGemmArgs a{};
+    fill_fwd_args(d, a);
+    return p32_eligible(a) ? 1 : 0;
+}
+
+extern "C" size_t mstg_conv2d_fwd_norm_workspace_bytes(const mstg_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    IGemmArgs a{};
+    fill_fwd_args(d, a);
+    return p32_eligible(a) ? p32_norm_workspace_bytes(a) : 0;
+}
+
+extern "C" int mstg_conv2d_fwd_norm(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias,
+                                    float* y, float* out_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    if (!x || !w || !y) return fail_arg(MSTG_E_BADARG, "conv_fwd_norm: null pointer");
+    IGemmArgs a{};
+    fill_fwd_args(d, a);
+    a.x = x; a.y = y; a.w = w; a.bias = bias;
+    if (!p32_eligible(a)) return fail_arg(MSTG_E_UNSUPPORTED, "conv_fwd_norm: only the layers mstg_conv2d_fwd_norm_supported() reports");
+    return launch_p32_norm(a, in_stats, out_stats, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
                                  size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d)) return rc;

@@ -45,6 +45,8 @@ struct P32Args {
     float* y;
     const float* wpk;   // [step][frag][lane][4]
     const float* bias;  // [16 * NF], zeros for an input gradient
+    const float* in_stats;  // nullable [N][Cin][2] (mean, rstd): the source is normalised + ReLU'd while it is staged
+    float* partial;         // STATS kernels: [N][workgroups][2][16 * NF] sums / sums of squares of what the workgroup wrote (zeroed by the host)
     int N, H, W, Cin, Ho, Wo, Cout, Gh, Gw, tiles_x, tiles_y, dbg;
 };
 
@@ -100,7 +102,22 @@ __device__ __forceinline__ void p32_fetch(const P32Args& a, const P32Plan& p, in
     }
 }
 
-template <int RPW, int NF, int NPF, bool WLDS>
+template <int CTRL>
+__device__ __forceinline__ float p32_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float p32_row16_sum(float v) {
+    v += p32_dpp<0xB1>(v);
+    v += p32_dpp<0x4E>(v);
+    v += p32_dpp<0x141>(v);
+    v += p32_dpp<0x140>(v);
+    return v;
+}
+
+// STATS: the epilogue also sums what it stores (InstanceNorm statistics of the output without another pass over it); a.in_stats:
+// the source is the RAW tensor in front of an InstanceNorm + ReLU, normalised while the patch is committed to LDS (zero padding
+// applies to the normalised tensor, as in the reference where the convolution pads what the norm produced).
+template <int RPW, int NF, int NPF, bool WLDS, bool STATS>
 __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P32Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 4 * RPW;
@@ -142,6 +159,32 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             rel[k] = (unsigned)(((r * a.W + c) * a.Cin + 4 * o) * 4);
         }
     }
+    float ssum[STATS ? NF : 1][4], ssq[STATS ? NF : 1][4];
+#pragma unroll
+    for (int f = 0; f < (STATS ? NF : 1); ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ssum[f][q] = ssq[f][q] = 0.f;
+    auto flush_stats = [&](int n_img) {  // between tiles only (the scratch aliases the patch); ends with a barrier
+        float* red = reinterpret_cast<float*>(patch);  // [4 waves][2][16 * NF]
+#pragma unroll
+        for (int f = 0; f < (STATS ? NF : 1); ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = p32_row16_sum(ssum[f][q]), s2 = p32_row16_sum(ssq[f][q]);
+                if (nl == 0) {
+                    red[(wv * 2 + 0) * 16 * NF + 16 * f + 4 * g + q] = s1;
+                    red[(wv * 2 + 1) * 16 * NF + 16 * f + 4 * g + q] = s2;
+                }
+                ssum[f][q] = ssq[f][q] = 0.f;
+            }
+        __syncthreads();
+        if (tid < 2 * 16 * NF)
+            a.partial[((size_t)n_img * G + blockIdx.x) * 2 * 16 * NF + tid] = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
+        __syncthreads();
+    };
+    int cur_n = -1;
+    float nsc[4], nnb[4];  // in_stats: (x - mean) * rstd = x * nsc + nnb for this thread's channel quad of image cur_in
+    int cur_in = -1;
     const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 4;  // bytes between this wave's consecutive rows
     P32Regs<NPF> R;
     int it = 0;
@@ -151,10 +194,24 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
         const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
         const int gy0 = ty * TH, gx0 = tx * P32_TW;
+        if (STATS && n != cur_n) {
+            if (cur_n >= 0) flush_stats(cur_n);
+            cur_n = n;
+        }
+        if (a.in_stats && n != cur_in) {
+            const float* st = a.in_stats + ((size_t)n * a.Cin + 4 * o) * 2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { nsc[c] = st[2 * c + 1]; nnb[c] = -st[2 * c] * st[2 * c + 1]; }
+            cur_in = n;
+        }
 #pragma unroll
         for (int k = 0; k < NPF; ++k)
             if (((vmask >> k) & 1) && !(a.dbg & 8)) {
                 f32x4 w = R.v[k];
+                if (a.in_stats) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = fmaxf(fmaf(w[c], nsc[c], nnb[c]), 0.f);
+                }
                 if (!((R.okmask >> k) & 1)) w = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;
             }
@@ -214,7 +271,13 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) *reinterpret_cast<f32x4*>(ybase + r * out_row + out_off0 + 64 * f) = acc[r][f];
+                    for (int f = 0; f < NF; ++f) {
+                        if (STATS) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
+                        }
+                        *reinterpret_cast<f32x4*>(ybase + r * out_row + out_off0 + 64 * f) = acc[r][f];
+                    }
             } else {
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
@@ -223,8 +286,13 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
                         const int oy = gy * mul + oyc, ox = gx * mul + oxc;
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
-                            if (16 * f + 4 * g < a.Cout)
+                            if (16 * f + 4 * g < a.Cout) {
+                                if (STATS) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
+                                }
                                 *reinterpret_cast<f32x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g) = acc[r][f];
+                            }
                     }
                 }
             }
@@ -232,6 +300,32 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         __syncthreads();  // every wave is done with the patch
         ++it;
         t = tnext;
+    }
+    if (STATS && cur_n >= 0) flush_stats(cur_n);
+}
+
+// partial [N][G][2][CP] -> stats [N][C][2] = (mean, rstd); one workgroup per image, double accumulation, fixed order
+__global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int G, int CP,
+                                                                int C, float count) {
+    __shared__ double red[256 * 2];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int per_c = 256 / CP, c = tid % CP, sub = tid / CP;  // CP in {16, 32, 64} -> 16 / 8 / 4 threads share a channel
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = sub; b < G; b += per_c) {
+        const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
+        s1 += (double)pp[c];
+        s2 += (double)pp[CP + c];
+    }
+    red[tid * 2] = s1;
+    red[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (sub == 0 && c < C) {
+        for (int k = 1; k < per_c; ++k) { s1 += red[(k * CP + c) * 2]; s2 += red[(k * CP + c) * 2 + 1]; }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((size_t)n * C + c) * 2] = (float)mean;
+        stats[((size_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
 
@@ -338,8 +432,9 @@ size_t p32_workspace_bytes(const IGemmArgs& a) {
 }
 
 template <int RPW, int NF, int NPF>
-static int p32_launch_t(const P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st) {
-    auto kern = p.wlds ? conv_p32_kernel<RPW, NF, NPF, true> : conv_p32_kernel<RPW, NF, NPF, false>;
+static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st, float* out_stats) {
+    auto kern = out_stats ? (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, true> : conv_p32_kernel<RPW, NF, NPF, false, true>)
+                          : (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, false> : conv_p32_kernel<RPW, NF, NPF, false, false>);
     const void* kptr = reinterpret_cast<const void*>(kern);
     static const void* c_kern = nullptr;
     static size_t c_lds = 0;
@@ -354,26 +449,42 @@ static int p32_launch_t(const P32Args& a, const P32Plan& p, size_t lds, long til
     }
     long g_ = 256L * c_occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
+    if (out_stats && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)
+        return fail_arg(MSTG_E_LAUNCH, "conv_p32: clearing the statistics partials failed");
     hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32_kernel");
+    if (out_stats) {
+        hipLaunchKernelGGL(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
+                           (float)((size_t)a.Ho * a.Wo));
+        MSTG_CHECK_LAUNCH("p32_norm_finalize_kernel");
+    }
     return MSTG_OK;
 }
 
 template <int RPW, int NF>
-static int p32_launch_npf(const P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st) {
-    if (p.npf <= 4) return p32_launch_t<RPW, NF, 4>(a, p, lds, tiles, st);
-    if (p.npf <= 6) return p32_launch_t<RPW, NF, 6>(a, p, lds, tiles, st);
-    if (p.npf <= 8) return p32_launch_t<RPW, NF, 8>(a, p, lds, tiles, st);
-    if (p.npf <= 10) return p32_launch_t<RPW, NF, 10>(a, p, lds, tiles, st);
-    return p32_launch_t<RPW, NF, 12>(a, p, lds, tiles, st);
+static int p32_launch_npf(P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st, float* out_stats) {
+    if (p.npf <= 4) return p32_launch_t<RPW, NF, 4>(a, p, lds, tiles, st, out_stats);
+    if (p.npf <= 6) return p32_launch_t<RPW, NF, 6>(a, p, lds, tiles, st, out_stats);
+    if (p.npf <= 8) return p32_launch_t<RPW, NF, 8>(a, p, lds, tiles, st, out_stats);
+    if (p.npf <= 10) return p32_launch_t<RPW, NF, 10>(a, p, lds, tiles, st, out_stats);
+    return p32_launch_t<RPW, NF, 12>(a, p, lds, tiles, st, out_stats);
 }
 
-int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) {
+size_t p32_norm_workspace_bytes(const IGemmArgs& g) {  // packed filter + statistics partials [N][<= 1024 workgroups][2][Cout]
+    const size_t base = p32_workspace_bytes(g);
+    return base ? ((base + 255) & ~(size_t)255) + (size_t)g.N * 1024 * 2 * g.Co * sizeof(float) : 0;
+}
+
+int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) { return launch_p32_norm(g, nullptr, nullptr, workspace, workspace_bytes, st); }
+
+int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats, void* workspace, size_t workspace_bytes, hipStream_t st) {
     P32Plan p;
     if (int rc = p32_plan(g, p)) return rc;
-    const size_t need = 256 + (size_t)p.nsteps * p.NF * 1024;
+    const size_t need = out_stats ? p32_norm_workspace_bytes(g) : 256 + (size_t)p.nsteps * p.NF * 1024;
     if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "conv_p32: workspace too small for the packed filter");
     P32Args a;
+    a.in_stats = in_stats;
+    a.partial = out_stats ? (float*)((char*)workspace + ((256 + (size_t)p.nsteps * p.NF * 1024 + 255) & ~(size_t)255)) : nullptr;
     a.x = g.x; a.y = g.y;
     a.bias = (const float*)workspace;
     a.wpk = (const float*)((const char*)workspace + 256);
@@ -392,7 +503,8 @@ int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipS
     MSTG_CHECK_LAUNCH("p32_pack_kernel");
     size_t lds = P32_TABLE_BYTES + (size_t)p.PH * p.PW * p.pixstride + (p.wlds ? (size_t)p.nsteps * p.NF * 1024 : 0);
     lds = (lds + 15) & ~(size_t)15;
-#define MSTG_P32_CASE(R_, F_) if (p.TH == 4 * R_ && p.NF == F_) return p32_launch_npf<R_, F_>(a, p, lds, tiles, st);
+    if (out_stats && lds < (size_t)P32_TABLE_BYTES + (p.wlds ? (size_t)p.nsteps * p.NF * 1024 : 0) + 8 * 16 * p.NF * sizeof(float)) lds += 8 * 16 * p.NF * sizeof(float);
+#define MSTG_P32_CASE(R_, F_) if (p.TH == 4 * R_ && p.NF == F_) return p32_launch_npf<R_, F_>(a, p, lds, tiles, st, out_stats);
     MSTG_P32_CASE(1, 1) MSTG_P32_CASE(2, 1) MSTG_P32_CASE(4, 1)
     MSTG_P32_CASE(1, 2) MSTG_P32_CASE(2, 2) MSTG_P32_CASE(4, 2)
     MSTG_P32_CASE(1, 4) MSTG_P32_CASE(2, 4)

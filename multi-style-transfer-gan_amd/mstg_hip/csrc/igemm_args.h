@@ -35,6 +35,10 @@ struct IGemmArgs {
 bool p32_eligible(const IGemmArgs& a);
 size_t p32_workspace_bytes(const IGemmArgs& a);
 int launch_p32(const IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st);
+// the same launch with InstanceNorm folded in on either side: in_stats (nullable) = (mean, rstd) of the raw source, normalised +
+// ReLU'd while staged; out_stats (nullable) = (mean, rstd) of the output, summed in the epilogue
+size_t p32_norm_workspace_bytes(const IGemmArgs& a);
+int launch_p32_norm(const IGemmArgs& a, const float* in_stats, float* out_stats, void* workspace, size_t workspace_bytes, hipStream_t st);
 const char* p32_kernel_name(const IGemmArgs& a);
 
 }  // namespace mstg

@@ -249,6 +249,54 @@ class ConvFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+def conv_norm_supported(N, H, W, Cin, Cout, k, stride, pad, dil, transposed) -> bool:
+    """True where mstg_conv2d_fwd_norm runs (the persistent kernel's layers): the InstanceNorm that follows the convolution gets its
+    statistics from the convolution's epilogue, and one in front of it is applied while the convolution stages its input."""
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, transposed)
+    if Ho * Wo < 256:  # tiny maps: E[x^2] - E[x]^2 from fp32 sums is too coarse against eps when the variance is ~0; use the pass
+        return False
+    d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
+    return bool(_lib.load().mstg_conv2d_fwd_norm_supported(C.byref(d)))
+
+
+class ConvStatsFn(torch.autograd.Function):
+    """(y, stats) = conv(x, w) + b with stats[n][c] = (mean, rstd) of y taken in the convolution's epilogue (NHWC, no activation);
+    optional in_stats: x is the raw tensor in front of InstanceNorm + ReLU and is normalised while staged (the caller owns that
+    norm's backward).  stats is a non-differentiable output; the backward is ConvFn's, on the normalised input when in_stats is
+    given (recomputed by the consumers that need it: see MSFusionFn)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        lib = _lib.load()
+        k, stride, pad, dil, transposed = cfg
+        x, w = _req(x, "conv input"), _req(w, "conv weight")
+        b = None if b is None else _req(b, "conv bias")
+        N, H, W, Cin = x.shape
+        Cout = w.shape[1] if transposed else w.shape[0]
+        Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, transposed)
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        stats = torch.empty((N, Cout, 2), dtype=torch.float32, device=x.device)
+        d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
+        ws = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
+        fl, by = _conv_cost(d)
+        _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
+            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(x), None, _p(w), _p(b), _p(y), _p(stats), _p(ws), ws.numel() * 4, _stream()),
+            "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
+        ctx.cfg, ctx.dims, ctx.has_bias = (k, stride, pad, dil, transposed, 0, 0, ACT_NONE), (N, H, W, Cin, Ho, Wo, Cout), b is not None
+        ctx.prefs = (w, b)
+        ctx.save_for_backward(x, w, None)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        return ConvFn.backward(ctx, dy)
+
+
+def conv2d_stats(x, w, b, k, stride=1, pad=0, dil=1, transposed=False):
+    return ConvStatsFn.apply(x, w, b, (k, stride, pad, dil, int(transposed)))
+
+
 def conv2d(x, w, b, k, stride=1, pad=0, dil=1, transposed=False, x_nchw=False, y_nchw=False, act=ACT_NONE):
     return ConvFn.apply(x, w, b, (k, stride, pad, dil, int(transposed), int(x_nchw), int(y_nchw), act))
 
@@ -487,15 +535,16 @@ class NormLocalAttentionFn(torch.autograd.Function):
     instead of 3 + 5 tensor passes -- and the normalised tensor is never stored."""
 
     @staticmethod
-    def forward(ctx, x, wqkv, bqkv, wproj, bproj):
+    def forward(ctx, x, wqkv, bqkv, wproj, bproj, stats=None):
         lib = _lib.load()
         x = _req(x, "norm input")
         wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
         N, H, W, Cn = x.shape
-        stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
-        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
-        _timed("norm_act_fwd", 0, 4 * x.numel(), lambda: _lib.check(
-            lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
+        if stats is None:  # no producer epilogue delivered them: one pass over x
+            stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+            _timed("norm_act_fwd", 0, 4 * x.numel(), lambda: _lib.check(
+                lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty_like(x)
         _timed(f"attn_fused_fwd_kernel<{Cn}>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
@@ -525,7 +574,7 @@ class NormLocalAttentionFn(torch.autograd.Function):
                 "mstg_norm_bwd_apply"))
         c2 = Cn * Cn
         return (dx, flat[:3 * c2].view(3 * Cn, Cn, 1, 1), flat[4 * c2:4 * c2 + 3 * Cn], flat[3 * c2:4 * c2].view(Cn, Cn, 1, 1),
-                flat[4 * c2 + 3 * Cn:])
+                flat[4 * c2 + 3 * Cn:], None)
 
 
 def fused_attention_supported(Cn: int) -> bool:

@@ -82,3 +82,43 @@ def test_norm_attention_many_images_per_wave():
             outs.append((y.detach().cpu(), t[0].grad.cpu()))
         assert torch.equal(outs[0][0], outs[1][0])
         report(f"norm+attn N{N} {H}x{W} dx vs chain", rel_l2(outs[0][1], outs[1][1]), 2e-6)
+
+
+def test_conv_epilogue_statistics_not_offered_for_tiny_maps():
+    from mstg_hip import ops
+    assert not ops.conv_norm_supported(1, 2, 2, 16, 16, 4, 2, 1, 1, 0)   # one output pixel: the variance is 0, eps decides
+    assert not ops.conv_norm_supported(2, 16, 16, 16, 16, 4, 2, 1, 1, 0)  # 64 output pixels
+    assert ops.conv_norm_supported(2, 32, 32, 16, 16, 4, 2, 1, 1, 0)
+
+
+@pytest.mark.parametrize("tr,N,H,W,Ci,Co", [(0, 3, 40, 36, 16, 32), (0, 2, 64, 64, 32, 64), (1, 3, 9, 11, 64, 32), (1, 2, 32, 32, 32, 16),
+                                             (0, 1, 32, 32, 16, 16)])
+def test_conv_epilogue_statistics(tr, N, H, W, Ci, Co):
+    """InstanceNorm statistics from the convolution's epilogue (mstg_conv2d_fwd_norm): the output is bit-identical to the plain
+    launch, (mean, rstd) agree with the statistics pass over that output and with torch's fp64 values, gradients are ConvFn's."""
+    from mstg_hip import _lib, ops
+    x = rnd((N, H, W, Ci), 21, 1.5) + 0.3
+    w = rnd((Ci, Co, 4, 4) if tr else (Co, Ci, 4, 4), 22, (Ci * 16) ** -0.5)
+    b = rnd((Co,), 23, 0.5)
+    assert ops.conv_norm_supported(N, H, W, Ci, Co, 4, 2, 1, 1, tr)
+    t = [v.to(DEV).requires_grad_(True) for v in (x, w, b)]
+    y, stats = ops.conv2d_stats(t[0], t[1], t[2], 4, 2, 1, 1, transposed=bool(tr))
+    t2 = [v.to(DEV).requires_grad_(True) for v in (x, w, b)]
+    y2 = ops.conv2d(t2[0], t2[1], t2[2], 4, 2, 1, 1, transposed=bool(tr))
+    assert torch.equal(y, y2)
+    lib = _lib.load()
+    Ho, Wo = y.shape[1], y.shape[2]
+    ref = torch.empty_like(stats)
+    ws = torch.empty(lib.mstg_norm_workspace_bytes(N, Ho * Wo, Co) // 4 + 1, dtype=torch.float32, device=DEV)
+    _lib.check(lib.mstg_norm_stats(y2.data_ptr(), ref.data_ptr(), N, Ho * Wo, Co, ws.data_ptr(), ws.numel() * 4, 0), "mstg_norm_stats")
+    y64 = y2.detach().cpu().double()
+    mean64 = y64.mean(dim=(1, 2))
+    rstd64 = (y64.var(dim=(1, 2), unbiased=False) + 1e-5).rsqrt()
+    report(f"epilogue stats mean  T{tr} {Ci}->{Co} {H}x{W}", rel_l2(stats[..., 0].cpu().double(), mean64), 2e-6)
+    report(f"epilogue stats rstd  T{tr} {Ci}->{Co} {H}x{W}", rel_l2(stats[..., 1].cpu().double(), rstd64), 2e-6)
+    report(f"epilogue vs pass     T{tr} {Ci}->{Co} {H}x{W}", rel_l2(stats.cpu(), ref.cpu()), 2e-6)
+    gy = rnd(tuple(y.shape), 24).to(DEV)
+    g1 = torch.autograd.grad((y * gy).sum(), t)
+    g2 = torch.autograd.grad((y2 * gy).sum(), t2)
+    for a_, b_ in zip(g1, g2):
+        assert torch.equal(a_, b_)
