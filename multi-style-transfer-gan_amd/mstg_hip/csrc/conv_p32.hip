@@ -20,10 +20,9 @@
 #include "igemm_args.h"
 
 namespace mstg {
-namespace {
 
-struct TrueT { static constexpr bool value = true; };
-struct FalseT { static constexpr bool value = false; };
+struct P32True { static constexpr bool value = true; };
+struct P32False { static constexpr bool value = false; };
 
 constexpr int P32_MAX_STEPS = 64;
 constexpr int P32_MAX_SEG = 4;
@@ -250,18 +249,18 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             load_ops(k0, s0, bA, aA);
             k0 = load_ko(clip(s0 + 2));
             load_ops(k1, clip(s0 + 1), bB, aB);
-            mma_step(bA, aA, TrueT{});  // accumulators start from the bias (the MFMA's C operand)
+            mma_step(bA, aA, P32True{});  // accumulators start from the bias (the MFMA's C operand)
             int s = s0 + 1;  // invariant: B holds the operands of step s (if s < s1), k0 the offset of step s + 1
             if (a.dbg & 1) s = s1;  // experiments (MSTG_P32_DBG): 1 one K-step only, 2 no stores, 4 no patch fetch, 8 no patch commit
             for (; s + 1 < s1; s += 2) {
                 k1 = load_ko(clip(s + 2));
                 load_ops(k0, s + 1, bA, aA);
-                mma_step(bB, aB, FalseT{});
+                mma_step(bB, aB, P32False{});
                 k0 = load_ko(clip(s + 3));
                 load_ops(k1, clip(s + 2), bB, aB);
-                mma_step(bA, aA, FalseT{});
+                mma_step(bA, aA, P32False{});
             }
-            if (s < s1) mma_step(bB, aB, FalseT{});
+            if (s < s1) mma_step(bB, aB, P32False{});
             // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) --------
             const int mul = up ? 2 : 1;
             if (a.dbg & 2) continue;
@@ -328,8 +327,6 @@ __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __r
         stats[((size_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
-
-}  // namespace
 
 // ---- host -------------------------------------------------------------------------------------------------------------------
 static int p32_plan(const IGemmArgs& a, P32Plan& p);
