@@ -433,17 +433,19 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
     auto kern = out_stats ? (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, true> : conv_p32_kernel<RPW, NF, NPF, false, true>)
                           : (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, false> : conv_p32_kernel<RPW, NF, NPF, false, false>);
     const void* kptr = reinterpret_cast<const void*>(kern);
-    static const void* c_kern = nullptr;
-    static size_t c_lds = 0;
-    static int c_occ = 1;
-    if (c_kern != kptr || c_lds != lds) {
+    // persistent workgroups: what a CU really holds of this kernel at this LDS size (registers, LDS), at most 4.  One slot per
+    // (filter in LDS, statistics) variant; a race between threads recomputes the same value.
+    static size_t c_lds_tab[4] = {0, 0, 0, 0};
+    static int c_occ_tab[4] = {0, 0, 0, 0};
+    const int slot = (p.wlds ? 1 : 0) + (out_stats ? 2 : 0);
+    if (!c_occ_tab[slot] || c_lds_tab[slot] != lds) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         int nb = 1;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kptr, 256, lds) != hipSuccess || nb < 1) nb = 1;
-        c_occ = nb > 4 ? 4 : nb;
-        c_kern = kptr;
-        c_lds = lds;
+        c_lds_tab[slot] = lds;
+        c_occ_tab[slot] = nb > 4 ? 4 : nb;
     }
+    const int c_occ = c_occ_tab[slot];
     long g_ = 256L * c_occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
     if (out_stats && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)
@@ -460,10 +462,9 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
 
 template <int RPW, int NF>
 static int p32_launch_npf(P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st, float* out_stats) {
-    if (p.npf <= 4) return p32_launch_t<RPW, NF, 4>(a, p, lds, tiles, st, out_stats);
+    // prefetch registers per thread: the layers of the path need 6 (16-channel stride-2 / 32-channel class patches), 8 (1x1) or 12
     if (p.npf <= 6) return p32_launch_t<RPW, NF, 6>(a, p, lds, tiles, st, out_stats);
     if (p.npf <= 8) return p32_launch_t<RPW, NF, 8>(a, p, lds, tiles, st, out_stats);
-    if (p.npf <= 10) return p32_launch_t<RPW, NF, 10>(a, p, lds, tiles, st, out_stats);
     return p32_launch_t<RPW, NF, 12>(a, p, lds, tiles, st, out_stats);
 }
 
@@ -513,7 +514,7 @@ const char* p32_kernel_name(const IGemmArgs& a) {
     static thread_local char name[64];
     P32Plan p;
     if (p32_plan(a, p)) return "";
-    snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s>", p.TH / 4, p.NF, p.npf <= 4 ? 4 : (p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : (p.npf <= 10 ? 10 : 12))),
+    snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s>", p.TH / 4, p.NF, p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : 12),
              p.wlds ? "true" : "false");
     return name;
 }
