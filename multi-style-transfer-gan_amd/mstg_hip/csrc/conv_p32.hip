@@ -328,12 +328,209 @@ __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __r
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// Image-source variant: stride-1 K x K convolution from an NCHW tensor with <= 4 channels (the RGB image at the stem, the RGB
+// gradient at the head's input gradient) to 16 NHWC channels.  The patch is staged as [pixel][4 floats]; a K-step covers FOUR taps
+// (lane group g reads the 16 bytes of tap 4s + g at its pixel) and issues three MFMAs (channel 3 is padding): a 7x7 filter costs
+// 13 x 3 = 39 MFMAs per 16 pixels instead of the 49 of the one-tap-per-MFMA mapping.  Everything else is conv_p32_kernel's scheme.
+// -------------------------------------------------------------------------------------------------------------------------
+constexpr int P32I_MAX_STEPS = 16, P32I_TH = 16, P32I_NPX = 2;  // 22 x 22 patch pixels of a 7x7 filter = 484 <= 2 per thread
+
+struct P32iPlan {
+    int nsteps, K, pad, PH, PW, flip;
+    unsigned koff[P32I_MAX_STEPS][4];
+    unsigned m_pw, m_ntile, m_tx;
+};
+
+__global__ void p32i_pack_kernel(const P32iPlan p, const float* __restrict__ w, const float* __restrict__ bias, int w_so, int w_sr, int Cin,
+                                 float* __restrict__ wpk, float* __restrict__ bpk) {
+    const int total = p.nsteps * 64 * 4, T = p.K * p.K;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int j = e & 3, lane = (e >> 2) & 63, s = e >> 8;
+        const int co = lane & 15, t = 4 * s + (lane >> 4);
+        float v = 0.f;
+        if (t < T && j < Cin) v = w[(size_t)co * w_so + (size_t)j * w_sr + (p.flip ? T - 1 - t : t)];
+        wpk[e] = v;
+    }
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 16; c += gridDim.x * blockDim.x) bpk[c] = bias ? bias[c] : 0.f;
+}
+
+struct P32iRegs {
+    float v[P32I_NPX][3];
+    unsigned okmask;
+};
+
+__device__ __forceinline__ void p32i_fetch(const P32Args& a, const P32iPlan& p, int t, int tid, P32iRegs& R) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+    const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+    const int sy0 = ty * P32I_TH - p.pad, sx0 = tx * P32_TW - p.pad;
+    const size_t plane = (size_t)a.H * a.W;
+    const float* img = a.x + (size_t)n * a.Cin * plane;
+    R.okmask = 0;
+#pragma unroll
+    for (int k = 0; k < P32I_NPX; ++k) {
+        const int e = 256 * k + tid;
+        const int r = (int)__umulhi((unsigned)e, p.m_pw), c = e - r * p.PW;
+        const int iy = sy0 + r, ix = sx0 + c;
+        const bool ok = e < p.PH * p.PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        R.okmask |= (unsigned)ok << k;
+        const unsigned off = ok ? (unsigned)(iy * a.W + ix) : 0u;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) R.v[k][ch] = img[off + (ch < a.Cin ? ch * plane : 0)];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv_p32i_kernel(const P32Args a, const P32iPlan p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPW = P32I_TH / 4, TH = P32I_TH;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, g = lane >> 4;
+    const int ntile = a.tiles_x * a.tiles_y, total_tiles = a.N * ntile, G = gridDim.x;
+    unsigned char* wl = smem + P32I_MAX_STEPS * 16;            // filter [step][lane][4]
+    unsigned char* patch = wl + (size_t)p.nsteps * 1024;        // [PH][PW][4 floats]
+    if (tid < P32I_MAX_STEPS * 4) reinterpret_cast<unsigned*>(smem)[tid] = p.koff[tid >> 2][tid & 3];
+    for (int e = tid; e < p.nsteps * 64; e += 256) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(a.wpk)[e];
+    const unsigned char* wlds_lane = wl + 16 * lane;
+    unsigned base[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) base[r] = (unsigned)(((RPW * wv + r) * p.PW + nl) * 16);
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 4 * g);
+    const size_t out_row = (size_t)a.Wo * 16 * 4;
+    P32iRegs R;
+    int it = 0;
+    int t = p32_tile(it, blockIdx.x, G);
+    if (t < total_tiles) p32i_fetch(a, p, t, tid, R);
+    const int nsteps = p.nsteps;
+    while (t < total_tiles) {
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+        const int gy0 = ty * TH, gx0 = tx * P32_TW;
+#pragma unroll
+        for (int k = 0; k < P32I_NPX; ++k) {
+            const int e = 256 * k + tid;
+            if (e < p.PH * p.PW) {
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                if ((R.okmask >> k) & 1) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) w[ch] = ch < a.Cin ? R.v[k][ch] : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(patch + 16 * e) = w;
+            }
+        }
+        __syncthreads();
+        const int tnext = p32_tile(it + 1, blockIdx.x, G);
+        if (tnext < total_tiles) p32i_fetch(a, p, tnext, tid, R);
+
+        f32x4 acc[RPW];
+        auto load_ko = [&](int s) -> unsigned { return reinterpret_cast<const unsigned*>(smem)[4 * s + g]; };
+        auto load_ops = [&](unsigned ko, int s, f32x4 (&bf)[RPW], f32x4& af) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) bf[r] = *reinterpret_cast<const f32x4*>(patch + base[r] + ko);
+            af = *reinterpret_cast<const f32x4*>(wlds_lane + (size_t)s * 1024);
+        };
+        auto mma_step = [&](const f32x4 (&bf)[RPW], const f32x4& af, auto from_bias) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[r][j], (decltype(from_bias)::value && j == 0) ? b4 : acc[r], 0, 0, 0);
+        };
+        auto clip = [&](int s) { return s < nsteps ? s : nsteps - 1; };
+        f32x4 bA[RPW], bB[RPW], aA, aB;
+        unsigned k0 = load_ko(0), k1 = load_ko(clip(1));
+        load_ops(k0, 0, bA, aA);
+        k0 = load_ko(clip(2));
+        load_ops(k1, clip(1), bB, aB);
+        mma_step(bA, aA, P32True{});
+        int s = 1;
+        for (; s + 1 < nsteps; s += 2) {
+            k1 = load_ko(clip(s + 2));
+            load_ops(k0, s + 1, bA, aA);
+            mma_step(bB, aB, P32False{});
+            k0 = load_ko(clip(s + 3));
+            load_ops(k1, clip(s + 2), bB, aB);
+            mma_step(bA, aA, P32False{});
+        }
+        if (s < nsteps) mma_step(bB, aB, P32False{});
+        if (gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw) {
+            char* ybase = reinterpret_cast<char*>(a.y) + (((size_t)n * a.Ho + gy0 + RPW * wv) * a.Wo + gx0 + nl) * 64 + 16 * g;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) *reinterpret_cast<f32x4*>(ybase + r * out_row) = acc[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int gy = gy0 + RPW * wv + r, gx = gx0 + nl;
+                if (gy < a.Gh && gx < a.Gw) *reinterpret_cast<f32x4*>(a.y + (((size_t)n * a.Ho + gy) * a.Wo + gx) * 16 + 4 * g) = acc[r];
+            }
+        }
+        __syncthreads();
+        ++it;
+        t = tnext;
+    }
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------------
 static int p32_plan(const IGemmArgs& a, P32Plan& p);
+
+static bool p32i_eligible(const IGemmArgs& a) {
+    return a.x_nchw && !a.y_nchw && a.Cr <= 3 && a.x_coff == 0 && a.x_ctot == a.Cr && a.Co == 16 && a.y_ctot == 16 && a.y_coff == 0 &&
+           a.KH == a.KW && a.KH >= 3 && a.KH * a.KW <= 4 * P32I_MAX_STEPS && a.stride == 1 && a.dil == 1 && !a.phase && !a.accumulate &&
+           a.act == MSTG_ACT_NONE && (a.KH + P32I_TH - 1) * (a.KW + P32_TW - 1) <= 256 * P32I_NPX && (size_t)a.H * a.W < ((size_t)1 << 30);
+}
+
+static void p32i_plan(const IGemmArgs& a, P32iPlan& p) {
+    memset(&p, 0, sizeof(p));
+    p.K = a.KH; p.pad = a.pad; p.flip = a.flip;
+    p.PH = P32I_TH + p.K - 1; p.PW = P32_TW + p.K - 1;
+    p.nsteps = cdiv(p.K * p.K, 4);
+    for (int s = 0; s < p.nsteps; ++s)
+        for (int g = 0; g < 4; ++g) {
+            const int t = 4 * s + g < p.K * p.K ? 4 * s + g : 0;  // beyond the filter: any valid pixel, the packed weights are zero
+            p.koff[s][g] = (unsigned)(((t / p.K) * p.PW + t % p.K) * 16);
+        }
+    p.m_pw = magic_u32((unsigned)p.PW);
+}
+
+static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    P32iPlan p;
+    p32i_plan(g, p);
+    const size_t need = 256 + (size_t)p.nsteps * 1024;
+    if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "conv_p32i: workspace too small for the packed filter");
+    P32Args a{};
+    a.x = g.x; a.y = g.y;
+    a.bias = (const float*)workspace;
+    a.wpk = (const float*)((const char*)workspace + 256);
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cr; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Co;
+    a.Gh = g.Ho; a.Gw = g.Wo;
+    a.tiles_y = cdiv(a.Gh, P32I_TH);
+    a.tiles_x = cdiv(a.Gw, P32_TW);
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    if ((unsigned long long)(tiles + 4096) * (unsigned long long)(a.tiles_x * a.tiles_y) >= (1ull << 32))
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: tensor too large for the 32-bit tile arithmetic");
+    p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
+    p.m_tx = magic_u32((unsigned)a.tiles_x);
+    hipLaunchKernelGGL(p32i_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_CHECK_LAUNCH("p32i_pack_kernel");
+    const size_t lds = (size_t)P32I_MAX_STEPS * 16 + (size_t)p.nsteps * 1024 + (size_t)p.PH * p.PW * 16;
+    static int occ = 0;
+    static size_t occ_lds = 0;
+    if (!occ || occ_lds != lds) {
+        int nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(conv_p32i_kernel), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        occ = nb > 4 ? 4 : nb;
+        occ_lds = lds;
+    }
+    long g_ = 256L * occ;
+    if (g_ > tiles) g_ = (tiles + 7) & ~7L;
+    hipLaunchKernelGGL(conv_p32i_kernel, dim3((unsigned)g_), dim3(256), lds, st, a, p);
+    MSTG_CHECK_LAUNCH("conv_p32i_kernel");
+    return MSTG_OK;
+}
 
 bool p32_eligible(const IGemmArgs& a) {
     const char* e = env_get(ENV_P32);
     if (e && e[0] == '0') return false;
+    if (p32i_eligible(a)) return true;
     auto ch_ok = [](int c) { return c == 16 || c == 32 || c == 64; };
     if (a.x_nchw || a.y_nchw || a.x_coff || a.y_coff || a.x_ctot != a.Cr || a.y_ctot != a.Co) return false;
     if (!ch_ok(a.Cr) || !ch_ok(a.Co)) return false;
@@ -423,6 +620,7 @@ static int p32_plan(const IGemmArgs& a, P32Plan& p) {
 }
 
 size_t p32_workspace_bytes(const IGemmArgs& a) {
+    if (p32_eligible(a) && p32i_eligible(a)) return 256 + (size_t)cdiv(a.KH * a.KW, 4) * 1024;
     P32Plan p;
     if (!p32_eligible(a) || p32_plan(a, p)) return 0;  // (eligible implies a plan)
     return 256 + (size_t)p.nsteps * p.NF * 1024;
@@ -476,6 +674,10 @@ size_t p32_norm_workspace_bytes(const IGemmArgs& g) {  // packed filter + statis
 int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) { return launch_p32_norm(g, nullptr, nullptr, workspace, workspace_bytes, st); }
 
 int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (p32i_eligible(g)) {
+        if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: no InstanceNorm folding for the image-source variant");
+        return launch_p32i(g, workspace, workspace_bytes, st);
+    }
     P32Plan p;
     if (int rc = p32_plan(g, p)) return rc;
     const size_t need = out_stats ? p32_norm_workspace_bytes(g) : 256 + (size_t)p.nsteps * p.NF * 1024;
@@ -512,6 +714,7 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
 
 const char* p32_kernel_name(const IGemmArgs& a) {
     static thread_local char name[64];
+    if (p32i_eligible(a)) return "conv_p32i_kernel";
     P32Plan p;
     if (p32_plan(a, p)) return "";
     snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s>", p.TH / 4, p.NF, p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : 12),
