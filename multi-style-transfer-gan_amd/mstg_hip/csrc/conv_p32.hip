@@ -520,7 +520,9 @@ static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_byt
         occ = nb > 4 ? 4 : nb;
         occ_lds = lds;
     }
-    long g_ = 256L * occ;
+    int occ_ = occ;
+    { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < occ_) occ_ = atoi(e); }
+    long g_ = 256L * occ_;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
     hipLaunchKernelGGL(conv_p32i_kernel, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32i_kernel");
@@ -643,7 +645,8 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
         c_lds_tab[slot] = lds;
         c_occ_tab[slot] = nb > 4 ? 4 : nb;
     }
-    const int c_occ = c_occ_tab[slot];
+    int c_occ = c_occ_tab[slot];
+    { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < c_occ) c_occ = atoi(e); }  // experiments: leave room for the other stream
     long g_ = 256L * c_occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
     if (out_stats && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)

@@ -1102,7 +1102,9 @@ static int launch_wp(WGradArgs& a, WpPlan& p, hipStream_t st) {
         occ = nb > 4 ? 4 : nb;
         occ_lds = p.lds;
     }
-    int S = (256 * occ) / p.ny;
+    int occ_ = occ;
+    { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < occ_) occ_ = atoi(e); }
+    int S = (256 * occ_) / p.ny;
     if (S > p.S) S = p.S;
     if (S < 1) S = 1;
     p.S = S;
@@ -1126,7 +1128,11 @@ static size_t w7_lds(const WGradArgs& a) {
     const size_t red = (size_t)14 * 256 * sizeof(float);
     return stage > red ? stage : red;
 }
-static int w7_splits(const WGradArgs& a) { return a.ntiles < 768 ? a.ntiles : 768; }
+static int w7_splits(const WGradArgs& a) {
+    int cap = 768;
+    { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < 3) cap = 256 * atoi(e); }
+    return a.ntiles < cap ? a.ntiles : cap;
+}
 static int launch_w7(WGradArgs& a, int S, hipStream_t st) {
     const size_t lds = w7_lds(a);
     if (a.mode == MODE_PACKX) hipLaunchKernelGGL((wgrad7_kernel<MODE_PACKX>), dim3(S), dim3(256), lds, st, a);
