@@ -469,6 +469,63 @@ __global__ __launch_bounds__(256) void conv_p32i_kernel(const P32Args a, const P
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// One output channel (the discriminator's score head, enhanced_generator.py:253-254: Conv2d(8C, 1, 4, 1, 1) on a 16 x 16 map): a
+// 16 x 16 MFMA tile would carry one useful row and a 32 x 15 x 15-pixel layer fills an eighth of the chip for 30 us.  Here a
+// workgroup owns one output row, thread (ox, tap) takes the dot product over the channels of its tap (filter transposed into
+// LDS), and the taps are summed in a fixed order: ~2000 multiply-adds per output, a few microseconds.
+// -------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_co1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int H, int W, int Cr, int Ho, int Wo, int KH, int KW, int pad,
+                                                       int w_sr) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int T = KH * KW, tid = threadIdx.x;
+    float* wl = sm;            // [T][Cr]
+    float* red = sm + T * Cr;  // [256]
+    for (int e = tid; e < T * Cr; e += 256) {
+        const int t = e / Cr, ci = e - t * Cr;
+        wl[e] = w[(size_t)ci * w_sr + t];
+    }
+    __syncthreads();
+    const int oy = blockIdx.x, n = blockIdx.y;
+    const int per = 256 / T, t = tid % T, slot = tid / T, ky = t / KW, kx = t - ky * KW;
+    const float b = bias ? bias[0] : 0.f;
+    for (int ox0 = 0; ox0 < Wo; ox0 += per) {
+        const int ox = ox0 + slot, iy = oy - pad + ky, ix = ox - pad + kx;
+        float acc = 0.f;
+        if (slot < per && ox < Wo && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+            const f32x4* xp = reinterpret_cast<const f32x4*>(x + (((size_t)n * H + iy) * W + ix) * Cr);
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + t * Cr);
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int c = 0; c < (Cr >> 2); ++c) a4 += xp[c] * wp[c];
+            acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        }
+        red[tid] = acc;
+        __syncthreads();
+        if (t == 0 && slot < per && ox < Wo) {
+            float sum = b;
+            for (int k = 0; k < T; ++k) sum += red[tid + k];
+            y[((size_t)n * Ho + oy) * Wo + ox] = sum;
+        }
+        __syncthreads();
+    }
+}
+
+static bool co1_eligible(const IGemmArgs& a) {
+    return a.Co == 1 && a.y_ctot == 1 && a.y_coff == 0 && !a.x_nchw && a.x_coff == 0 && a.x_ctot == a.Cr && (a.Cr & 3) == 0 && a.Cr >= 16 &&
+           a.stride == 1 && a.dil == 1 && !a.phase && !a.flip && !a.accumulate && a.act == MSTG_ACT_NONE && a.KH * a.KW <= 16 &&
+           (size_t)(a.KH * a.KW * a.Cr + 256) * sizeof(float) <= 64 * 1024 && a.Ho <= 65535 && a.N <= 65535;
+}
+
+static int launch_co1(const IGemmArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(a.KH * a.KW * a.Cr + 256) * sizeof(float);
+    hipLaunchKernelGGL(conv_co1_kernel, dim3(a.Ho, a.N), dim3(256), lds, st, a.x, a.w, a.bias, a.y, a.H, a.W, a.Cr, a.Ho, a.Wo, a.KH, a.KW,
+                       a.pad, a.w_sr);
+    MSTG_CHECK_LAUNCH("conv_co1_kernel");
+    return MSTG_OK;
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------------
 static int p32_plan(const IGemmArgs& a, P32Plan& p);
 
@@ -532,6 +589,7 @@ static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_byt
 bool p32_eligible(const IGemmArgs& a) {
     const char* e = env_get(ENV_P32);
     if (e && e[0] == '0') return false;
+    if (co1_eligible(a)) return true;
     if (p32i_eligible(a)) return true;
     auto ch_ok = [](int c) { return c == 16 || c == 32 || c == 64; };
     if (a.x_nchw || a.y_nchw || a.x_coff || a.y_coff || a.x_ctot != a.Cr || a.y_ctot != a.Co) return false;
@@ -622,6 +680,7 @@ static int p32_plan(const IGemmArgs& a, P32Plan& p) {
 }
 
 size_t p32_workspace_bytes(const IGemmArgs& a) {
+    if (p32_eligible(a) && co1_eligible(a)) return 16;  // no packed filter
     if (p32_eligible(a) && p32i_eligible(a)) return 256 + (size_t)cdiv(a.KH * a.KW, 4) * 1024;
     P32Plan p;
     if (!p32_eligible(a) || p32_plan(a, p)) return 0;  // (eligible implies a plan)
@@ -677,6 +736,10 @@ size_t p32_norm_workspace_bytes(const IGemmArgs& g) {  // packed filter + statis
 int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) { return launch_p32_norm(g, nullptr, nullptr, workspace, workspace_bytes, st); }
 
 int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (co1_eligible(g)) {
+        if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_co1: no InstanceNorm folding");
+        return launch_co1(g, st);
+    }
     if (p32i_eligible(g)) {
         if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: no InstanceNorm folding for the image-source variant");
         return launch_p32i(g, workspace, workspace_bytes, st);
@@ -717,6 +780,7 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
 
 const char* p32_kernel_name(const IGemmArgs& a) {
     static thread_local char name[64];
+    if (co1_eligible(a)) return "conv_co1_kernel";
     if (p32i_eligible(a)) return "conv_p32i_kernel";
     P32Plan p;
     if (p32_plan(a, p)) return "";
