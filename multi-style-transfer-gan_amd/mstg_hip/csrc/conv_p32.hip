@@ -784,8 +784,8 @@ const char* p32_kernel_name(const IGemmArgs& a) {
     if (p32i_eligible(a)) return "conv_p32i_kernel";
     P32Plan p;
     if (p32_plan(a, p)) return "";
-    snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s>", p.TH / 4, p.NF, p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : 12),
-             p.wlds ? "true" : "false");
+    snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s, false>", p.TH / 4, p.NF, p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : 12),
+             p.wlds ? "true" : "false");  // as rocprofv3 prints it; mstg_conv2d_fwd_norm with out_stats runs the <..., true> instantiation
     return name;
 }
 

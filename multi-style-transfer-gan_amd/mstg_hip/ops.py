@@ -279,7 +279,7 @@ class ConvStatsFn(torch.autograd.Function):
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
         ws = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
         fl, by = _conv_cost(d)
-        _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
+        _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(  # the STATS instantiation
             lib.mstg_conv2d_fwd_norm(C.byref(d), _p(x), None, _p(w), _p(b), _p(y), _p(stats), _p(ws), ws.numel() * 4, _stream()),
             "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
         ctx.cfg, ctx.dims, ctx.has_bias = (k, stride, pad, dil, transposed, 0, 0, ACT_NONE), (N, H, W, Cin, Ho, Wo, Cout), b is not None
@@ -505,7 +505,7 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_fwd_kernel<{Cn}, false>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_fwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_fwd"))
         ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj)
@@ -520,7 +520,7 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_bwd_kernel<{Cn}, false>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_bwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), _p(flat), N, H, W, Cn, _p(ws),
                                      ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
         c2 = Cn * Cn
@@ -546,7 +546,7 @@ class NormLocalAttentionFn(torch.autograd.Function):
             _timed("norm_act_fwd", 0, 4 * x.numel(), lambda: _lib.check(
                 lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_fwd_kernel<{Cn}, true>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_norm_fwd"))
         ctx.save_for_backward(x, stats, wqkv, bqkv, wproj, bproj)
@@ -563,7 +563,7 @@ class NormLocalAttentionFn(torch.autograd.Function):
         S = lib.mstg_window_attn_norm_sums_split()
         sums = torch.empty((N, S, 2, Cn), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_bwd_kernel<{Cn}, true>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_bwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz), _p(flat),
                                           _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_norm_bwd"))
         dx = None
