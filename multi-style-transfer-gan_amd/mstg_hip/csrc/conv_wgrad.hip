@@ -1075,7 +1075,7 @@ static bool wp_ok(const WGradArgs& a) {
     if (e && e[0] == '0') return false;
     return a.Teff == 16 && a.mode == MODE_PLAIN && a.stride == 2 && a.pad == 1 && a.dil == 1 && !a.g_nchw && !a.h_nchw && !a.g_coff &&
            !a.h_coff && a.g_ctot == a.Cg && a.h_ctot == a.Ch && a.Cg % 16 == 0 && a.Ch % (16 * WP_NFHT) == 0 && a.gH == 2 * a.hH &&
-           a.gW == 2 * a.hW && (size_t)a.gH * a.gW * a.Cg * 4 < ((size_t)1 << 32);
+           a.gW == 2 * a.hW && (size_t)a.gH * a.gW * a.Cg * 4 < ((size_t)1 << 32) && (size_t)a.hH * a.hW * a.Ch * 4 < ((size_t)1 << 32);
 }
 struct WpPlan { int S, ny; size_t lds, ws_bytes; };
 static WpPlan wp_plan(const WGradArgs& a) {  // a: after plan_ts (tiles for TH = 4)
