@@ -364,6 +364,16 @@ def main():
         roofline["measured"] = "instrumented step on one stream (MSTG_STREAMS=0 equivalent)"
         roofline.update({"kernel": sym, "launches_per_step": r["launches"], "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
                          "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2)})
+        # the largest timed CALL regardless of how many kernels it launches (the InstanceNorm backward = norm_partial_kernel<true> +
+        # norm_apply_kernel<true> is the largest share of the headline step): same arithmetic, so the reader sees both
+        lsym, lr = max(table.items(), key=lambda kv: kv[1]["ms"])
+        lt_mfma, lt_hbm = lr["flops"] / (peak_mfma * 1e12), lr["bytes"] / (PEAK_HBM_GBS * 1e9)
+        lsec = lr["ms"] / 1e3
+        roofline["largest_call"] = {"name": lsym, "launches_per_step": lr["launches"], "ms_per_step": round(lr["ms"], 3),
+                                    "share_of_gpu_time": round(lr["ms"] / total_ms, 3), "bound": "mfma" if lt_mfma >= lt_hbm else "hbm",
+                                    "achieved": round(lr["flops"] / lsec / 1e12, 3) if lt_mfma >= lt_hbm else round(lr["bytes"] / lsec / 1e9, 1),
+                                    "unit": "TFLOP/s" if lt_mfma >= lt_hbm else "GB/s",
+                                    "frac": round((lr["flops"] / lsec / 1e12) / peak_mfma if lt_mfma >= lt_hbm else (lr["bytes"] / lsec / 1e9) / PEAK_HBM_GBS, 4)}
         # whole-step view against both roofs (algorithmic work of every timed launch / wall time of the timed region)
         tot_fl, tot_by = sum(v["flops"] for v in table.values()), sum(v["bytes"] for v in table.values())
         roofline["step"] = {"algorithmic_tflop": round(tot_fl / 1e12, 4), "algorithmic_gb": round(tot_by / 1e9, 3),
