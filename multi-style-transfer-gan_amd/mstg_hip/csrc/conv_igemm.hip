@@ -1166,14 +1166,14 @@ extern "C" int mstg_conv2d_fwd_norm_supported(const mstg_conv_desc* d) {
     if (check_desc(d)) return 0;
     IGemmArgs a{};
     fill_fwd_args(d, a);
-    return p32_eligible(a) && !a.x_nchw && a.Co != 1 ? 1 : 0;
+    return p32_eligible(a) && !a.x_nchw && !a.y_nchw && a.Co != 1 ? 1 : 0;
 }
 
 extern "C" size_t mstg_conv2d_fwd_norm_workspace_bytes(const mstg_conv_desc* d) {
     if (check_desc(d)) return 0;
     IGemmArgs a{};
     fill_fwd_args(d, a);
-    return p32_eligible(a) && !a.x_nchw && a.Co != 1 ? p32_norm_workspace_bytes(a) : 0;
+    return p32_eligible(a) && !a.x_nchw && !a.y_nchw && a.Co != 1 ? p32_norm_workspace_bytes(a) : 0;
 }
 
 extern "C" int mstg_conv2d_fwd_norm(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias,
@@ -1183,7 +1183,7 @@ extern "C" int mstg_conv2d_fwd_norm(const mstg_conv_desc* d, const float* x, con
     IGemmArgs a{};
     fill_fwd_args(d, a);
     a.x = x; a.y = y; a.w = w; a.bias = bias;
-    if (!p32_eligible(a) || a.x_nchw || a.Co == 1) return fail_arg(MSTG_E_UNSUPPORTED, "conv_fwd_norm: only the layers mstg_conv2d_fwd_norm_supported() reports");
+    if (!p32_eligible(a) || a.x_nchw || a.y_nchw || a.Co == 1) return fail_arg(MSTG_E_UNSUPPORTED, "conv_fwd_norm: only the layers mstg_conv2d_fwd_norm_supported() reports");
     return launch_p32_norm(a, in_stats, out_stats, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

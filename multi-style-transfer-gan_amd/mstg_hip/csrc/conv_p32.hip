@@ -470,6 +470,216 @@ __global__ __launch_bounds__(256) void conv_p32i_kernel(const P32Args a, const P
 }
 
 // -------------------------------------------------------------------------------------------------------------------------
+// <= 4 output channels to an NCHW tensor (7x7 head forward with tanh, stem input gradient): the 16 rows of the MFMA tile are
+// (column shift delta = 0..3) x (4 channels), igemm_light's "dpack" mapping -- packed tap (ky, j) reads patch column p + 4j + 3
+// and row 4 delta + c carries the real tap kx = 4j + 3 - delta, so accumulator column p holds a partial sum of output column
+// p + delta; tiles advance 13 columns and an LDS exchange adds the four shifted partials.  4x fewer MFMAs than padding 3
+// channels to 16 rows; here in the persistent, pipelined form of conv_p32_kernel.
+// -------------------------------------------------------------------------------------------------------------------------
+struct P32dPlan {
+    int nsteps, K, pad, tapsx, PH, PW, pixstride, flip, npf;
+    unsigned koff[P32_MAX_STEPS];
+    int8_t tky[P32_MAX_STEPS], tj[P32_MAX_STEPS];
+    int16_t tcb[P32_MAX_STEPS];
+    unsigned m_pw, m_ntile, m_tx;
+};
+
+__global__ void p32d_pack_kernel(const P32dPlan p, const float* __restrict__ w, const float* __restrict__ bias, int w_so, int w_sr, int Co,
+                                 int Cin, float* __restrict__ wpk, float* __restrict__ bpk) {
+    const int total = p.nsteps * 64 * 4;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int jj = e & 3, lane = (e >> 2) & 63, s = e >> 8;
+        const int m = lane & 15, delta = m >> 2, c = m & 3, ci = p.tcb[s] + 4 * (lane >> 4) + jj;
+        const int kx = 4 * p.tj[s] + 3 - delta, real = p.tky[s] * p.K + kx;
+        float v = 0.f;
+        if (c < Co && ci < Cin && kx >= 0 && kx < p.K) v = w[(size_t)c * w_so + (size_t)ci * w_sr + (p.flip ? p.K * p.K - 1 - real : real)];
+        wpk[e] = v;
+    }
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 4; c += gridDim.x * blockDim.x) bpk[c] = (bias && c < Co) ? bias[c] : 0.f;
+}
+
+template <int NPF>
+__device__ __forceinline__ void p32d_fetch(const P32Args& a, const P32dPlan& p, int t, int TH, int tid, P32Regs<NPF>& R) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+    const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+    const int sy0 = ty * TH - p.pad, sx0 = tx * 13 - 3 - p.pad;
+    const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 4;
+    const int quads = a.Cin >> 2, sh = quads == 4 ? 2 : (quads == 8 ? 3 : 4), total = p.PH * p.PW * quads;
+    R.okmask = 0;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int e = 256 * k + tid, pix = e >> sh;
+        const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
+        const int iy = sy0 + r, ix = sx0 + c;
+        const bool ok = e < total && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        R.okmask |= (unsigned)ok << k;
+        R.v[k] = *reinterpret_cast<const f32x4*>(img + (ok ? (unsigned)(((iy * a.W + ix) * a.Cin + 4 * (e & (quads - 1))) * 4) : 0u));
+    }
+}
+
+template <int RPW, int NPF>
+__global__ __launch_bounds__(256) void conv_p32d_kernel(const P32Args a, const P32dPlan p, const int act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TH = 4 * RPW;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, g = lane >> 4;
+    const int ntile = a.tiles_x * a.tiles_y, total_tiles = a.N * ntile, G = gridDim.x;
+    unsigned char* wl = smem + 4 * P32_MAX_STEPS;
+    unsigned char* patch = wl + (size_t)p.nsteps * 1024;
+    if (tid < P32_MAX_STEPS) reinterpret_cast<unsigned*>(smem)[tid] = p.koff[tid];
+    for (int e = tid; e < p.nsteps * 64; e += 256) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(a.wpk)[e];
+    const unsigned char* wlds_lane = wl + 16 * lane;
+    unsigned base[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) base[r] = (unsigned)(((RPW * wv + r) * p.PW + nl) * p.pixstride + 16 * g);
+    const int quads = a.Cin >> 2, o = tid & (quads - 1), sh = quads == 4 ? 2 : (quads == 8 ? 3 : 4), total = p.PH * p.PW * quads;
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias);
+    const int nsteps = p.nsteps;
+    P32Regs<NPF> R;
+    int it = 0;
+    int t = p32_tile(it, blockIdx.x, G);
+    if (t < total_tiles) p32d_fetch<NPF>(a, p, t, TH, tid, R);
+    while (t < total_tiles) {
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int e = 256 * k + tid;
+            if (e < total) *reinterpret_cast<f32x4*>(patch + (unsigned)((e >> sh) * p.pixstride + 16 * o)) = ((R.okmask >> k) & 1) ? R.v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        const int tnext = p32_tile(it + 1, blockIdx.x, G);
+        if (tnext < total_tiles) p32d_fetch<NPF>(a, p, tnext, TH, tid, R);
+
+        f32x4 acc[RPW];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_ko = [&](int s) -> unsigned { return reinterpret_cast<const unsigned*>(smem)[s]; };
+        auto load_ops = [&](unsigned ko, int s, f32x4 (&bf)[RPW], f32x4& af) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) bf[r] = *reinterpret_cast<const f32x4*>(patch + base[r] + ko);
+            af = *reinterpret_cast<const f32x4*>(wlds_lane + (size_t)s * 1024);
+        };
+        auto mma_step = [&](const f32x4 (&bf)[RPW], const f32x4& af) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[r][j], acc[r], 0, 0, 0);
+        };
+        auto clip = [&](int s) { return s < nsteps ? s : nsteps - 1; };
+        f32x4 bA[RPW], bB[RPW], aA, aB;
+        unsigned k0 = load_ko(0), k1 = load_ko(clip(1));
+        load_ops(k0, 0, bA, aA);
+        k0 = load_ko(clip(2));
+        load_ops(k1, clip(1), bB, aB);
+        mma_step(bA, aA);
+        int s = 1;
+        for (; s + 1 < nsteps; s += 2) {
+            k1 = load_ko(clip(s + 2));
+            load_ops(k0, s + 1, bA, aA);
+            mma_step(bB, aB);
+            k0 = load_ko(clip(s + 3));
+            load_ops(k1, clip(s + 2), bB, aB);
+            mma_step(bA, aA);
+        }
+        if (s < nsteps) mma_step(bB, aB);
+        // ---- y[q][c] = sum_delta D[delta][q - delta]: exchange through LDS (the patch is dead), lanes (row g, column nl < 13) finish -------
+        __syncthreads();
+        float* comb = reinterpret_cast<float*>(patch) + wv * (256 * RPW);  // [row][delta][p][4]
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) *reinterpret_cast<f32x4*>(&comb[((r * 4 + g) * 16 + nl) * 4]) = acc[r];
+        __syncthreads();
+        if (g < RPW && nl < 13) {
+            f32x4 v = b4;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) v += *reinterpret_cast<const f32x4*>(&comb[((g * 4 + d) * 16 + nl + 3 - d) * 4]);
+            const int oy = ty * TH + RPW * wv + g, ox = tx * 13 + nl;
+            if (oy < a.Ho && ox < a.Wo) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < a.Cout) a.y[(((size_t)n * a.Cout + e) * a.Ho + oy) * a.Wo + ox] = apply_act(v[e], act);
+            }
+        }
+        __syncthreads();
+        ++it;
+        t = tnext;
+    }
+}
+
+static bool p32d_eligible(const IGemmArgs& a) {
+    if (!(a.y_nchw && !a.x_nchw && a.Co <= 4 && a.y_coff == 0 && a.y_ctot == a.Co && a.x_coff == 0 && a.x_ctot == a.Cr && a.Cr == 16 &&
+          a.KH == a.KW && a.KH >= 3 && a.KH <= 7 && a.stride == 1 && a.dil == 1 && !a.phase && !a.accumulate &&
+          (a.act == MSTG_ACT_NONE || a.act == MSTG_ACT_TANH)))
+        return false;
+    const char* e = env_get(ENV_NO_DPACK);
+    return !(e && e[0] == '1') && (size_t)a.H * a.W * a.Cr * 4 < ((size_t)1 << 32);
+}
+
+static void p32d_plan(const IGemmArgs& a, P32dPlan& p, int TH) {
+    memset(&p, 0, sizeof(p));
+    p.K = a.KH; p.pad = a.pad; p.flip = a.flip;
+    p.tapsx = cdiv(p.K, 4);
+    p.PH = TH + p.K - 1;
+    p.PW = 15 + 4 * p.tapsx;
+    p.pixstride = 4 * a.Cr + 32;
+    int s = 0;
+    for (int ky = 0; ky < p.K; ++ky)
+        for (int j = 0; j < p.tapsx; ++j, ++s) {
+            p.koff[s] = (unsigned)((ky * p.PW + 4 * j + 3) * p.pixstride);
+            p.tky[s] = (int8_t)ky; p.tj[s] = (int8_t)j; p.tcb[s] = 0;
+        }
+    p.nsteps = s;
+    p.m_pw = magic_u32((unsigned)p.PW);
+    p.npf = cdiv(p.PH * p.PW * (a.Cr / 4), 256);
+}
+
+template <int RPW, int NPF>
+static int p32d_launch_t(const P32Args& a, const P32dPlan& p, int act, size_t lds, long tiles, hipStream_t st) {
+    auto kern = conv_p32d_kernel<RPW, NPF>;
+    static int occ = 0;
+    static size_t occ_lds = 0;
+    if (!occ || occ_lds != lds) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int nb = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || nb < 1) nb = 1;
+        occ = nb > 4 ? 4 : nb;
+        occ_lds = lds;
+    }
+    long g_ = 256L * occ;
+    if (g_ > tiles) g_ = (tiles + 7) & ~7L;
+    hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p, act);
+    MSTG_CHECK_LAUNCH("conv_p32d_kernel");
+    return MSTG_OK;
+}
+
+static int launch_p32d(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int TH = g.Ho >= 16 ? 16 : 8;
+    P32dPlan p;
+    p32d_plan(g, p, TH);
+    const size_t need = 256 + (size_t)p.nsteps * 1024;
+    if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "conv_p32d: workspace too small for the packed filter");
+    P32Args a{};
+    a.x = g.x; a.y = g.y;
+    a.bias = (const float*)workspace;
+    a.wpk = (const float*)((const char*)workspace + 256);
+    a.N = g.N; a.H = g.H; a.W = g.W; a.Cin = g.Cr; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = g.Co;
+    a.tiles_y = cdiv(g.Ho, TH);
+    a.tiles_x = cdiv(g.Wo, 13);
+    const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
+    if ((unsigned long long)(tiles + 4096) * (unsigned long long)(a.tiles_x * a.tiles_y) >= (1ull << 32))
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: tensor too large for the 32-bit tile arithmetic");
+    p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
+    p.m_tx = magic_u32((unsigned)a.tiles_x);
+    hipLaunchKernelGGL(p32d_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_CHECK_LAUNCH("p32d_pack_kernel");
+    size_t patch = (size_t)p.PH * p.PW * p.pixstride;
+    if (patch < (size_t)4 * 256 * (TH / 4) * sizeof(float)) patch = (size_t)4 * 256 * (TH / 4) * sizeof(float);  // the exchange tiles live there too
+    const size_t lds = 4 * P32_MAX_STEPS + (size_t)p.nsteps * 1024 + patch;
+    if (TH == 16) return p.npf <= 8 ? p32d_launch_t<4, 8>(a, p, g.act, lds, tiles, st) : fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: patch too large");
+    return p.npf <= 6 ? p32d_launch_t<2, 6>(a, p, g.act, lds, tiles, st) : fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: patch too large");
+}
+
+// -------------------------------------------------------------------------------------------------------------------------
 // One output channel (the discriminator's score head, enhanced_generator.py:253-254: Conv2d(8C, 1, 4, 1, 1) on a 16 x 16 map): a
 // 16 x 16 MFMA tile would carry one useful row and a 32 x 15 x 15-pixel layer fills an eighth of the chip for 30 us.  Here a
 // workgroup owns one output row, thread (ox, tap) takes the dot product over the channels of its tap (filter transposed into
@@ -591,6 +801,7 @@ bool p32_eligible(const IGemmArgs& a) {
     if (e && e[0] == '0') return false;
     if (co1_eligible(a)) return true;
     if (p32i_eligible(a)) return true;
+    if (p32d_eligible(a)) return true;
     auto ch_ok = [](int c) { return c == 16 || c == 32 || c == 64; };
     if (a.x_nchw || a.y_nchw || a.x_coff || a.y_coff || a.x_ctot != a.Cr || a.y_ctot != a.Co) return false;
     if (!ch_ok(a.Cr) || !ch_ok(a.Co)) return false;
@@ -682,6 +893,7 @@ static int p32_plan(const IGemmArgs& a, P32Plan& p) {
 size_t p32_workspace_bytes(const IGemmArgs& a) {
     if (p32_eligible(a) && co1_eligible(a)) return 16;  // no packed filter
     if (p32_eligible(a) && p32i_eligible(a)) return 256 + (size_t)cdiv(a.KH * a.KW, 4) * 1024;
+    if (p32_eligible(a) && p32d_eligible(a)) return 256 + (size_t)a.KH * cdiv(a.KW, 4) * 1024;
     P32Plan p;
     if (!p32_eligible(a) || p32_plan(a, p)) return 0;  // (eligible implies a plan)
     return 256 + (size_t)p.nsteps * p.NF * 1024;
@@ -744,6 +956,10 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
         if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: no InstanceNorm folding for the image-source variant");
         return launch_p32i(g, workspace, workspace_bytes, st);
     }
+    if (p32d_eligible(g)) {
+        if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: no InstanceNorm folding");
+        return launch_p32d(g, workspace, workspace_bytes, st);
+    }
     P32Plan p;
     if (int rc = p32_plan(g, p)) return rc;
     const size_t need = out_stats ? p32_norm_workspace_bytes(g) : 256 + (size_t)p.nsteps * p.NF * 1024;
@@ -782,6 +998,7 @@ const char* p32_kernel_name(const IGemmArgs& a) {
     static thread_local char name[64];
     if (co1_eligible(a)) return "conv_co1_kernel";
     if (p32i_eligible(a)) return "conv_p32i_kernel";
+    if (p32d_eligible(a)) return a.Ho >= 16 ? "conv_p32d_kernel<4, 8>" : "conv_p32d_kernel<2, 6>";
     P32Plan p;
     if (p32_plan(a, p)) return "";
     snprintf(name, sizeof(name), "conv_p32_kernel<%d, %d, %d, %s, false>", p.TH / 4, p.NF, p.npf <= 6 ? 6 : (p.npf <= 8 ? 8 : 12),
