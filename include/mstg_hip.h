@@ -68,6 +68,12 @@ size_t mstg_conv2d_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_fwd(const mstg_conv_desc* d, const float* x, const float* w, const float* bias /*nullable*/,
                     float* y, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = d(loss)/d(module input), from dy = d(loss)/d(module output) */
+/* Weight gradient of a 1x1 Conv2d whose input is ReLU(InstanceNorm2d(x_raw)) (the MultiScaleBlock's fusion convolution behind the
+ * branch concat's norm, enhanced_generator.py:72-75, 83): x_raw is normalised with in_stats[n][c] = (mean, rstd) while the kernel
+ * stages it, so the normalised tensor need not exist.  Supported where a staged pixel run stays inside one image. */
+int mstg_conv2d_wgrad_norm_supported(const mstg_conv_desc* d);
+int mstg_conv2d_wgrad_norm(const mstg_conv_desc* d, const float* x_raw, const float* in_stats, const float* dy, float* dw, float* dbias,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* Forward with InstanceNorm folded in on either side, for the layers the persistent kernel covers (4x4 stride-2 Conv2d /
  * ConvTranspose2d and 1x1 Conv2d at 16 / 32 / 64 channels, unsliced NHWC, no fused activation): in_stats (nullable) = (mean, rstd)
  * [N][Cin][2] of the RAW source -- it is normalised and ReLU'd while staged, i.e. x is what stands in front of

@@ -75,8 +75,14 @@ class MultiScaleBlock(nn.Module):
         for br in (self.branch1, self.branch2, self.branch3, self.branch4):
             wb += [br[0].weight, br[0].bias]
         cat, xres = ops.MSBranchesFn.apply(x, *wb)    # 4 convs -> one (N,H,W,ch) buffer, no torch.cat; xres = x for the residual
-        cat = ops.instnorm_act(cat, ACT_RELU)          # per-channel IN: one launch covers all four branches
-        f = self.fusion[0](cat, nhwc=True)
+        conv = self.fusion[0]
+        if (os.environ.get("MSTG_NORM_FUSION", "1") != "0" and conv.kernel_size == (1, 1) and conv.out_channels == cat.shape[3]
+                and ops.ms_fusion_supported(cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3])):
+            # the concat's IN + ReLU folded into the fusion convolution: the normalised concat is never written
+            f = ops.MSFusionFn.apply(cat, conv.weight, conv.bias)
+        else:
+            cat = ops.instnorm_act(cat, ACT_RELU)      # per-channel IN: one launch covers all four branches
+            f = conv(cat, nhwc=True)
         return ops.instnorm_act(f, ACT_RELU, residual=xres)
 
     def forward(self, x):

@@ -48,6 +48,8 @@ SIGNATURES = {
     "mstg_window_attn_fused_supported": (_i, [_i]),
     "mstg_window_attn_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mstg_conv2d_wgrad_norm_supported": (_i, [_dp]),
+    "mstg_conv2d_wgrad_norm": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_conv2d_fwd_norm_supported": (_i, [_dp]),
     "mstg_conv2d_fwd_norm_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd_norm": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         __syncthreads();
     };
     int cur_n = -1;
-    float nsc[4], nnb[4];  // in_stats: (x - mean) * rstd = x * nsc + nnb for this thread's channel quad of image cur_in
+    float nsc[4], nnb[4];  // in_stats: (rstd, mean) of this thread's channel quad of image cur_in
     int cur_in = -1;
     const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 4;  // bytes between this wave's consecutive rows
     P32Regs<NPF> R;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         if (a.in_stats && n != cur_in) {
             const float* st = a.in_stats + ((size_t)n * a.Cin + 4 * o) * 2;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { nsc[c] = st[2 * c + 1]; nnb[c] = -st[2 * c] * st[2 * c + 1]; }
+            for (int c = 0; c < 4; ++c) { nsc[c] = st[2 * c + 1]; nnb[c] = st[2 * c]; }
             cur_in = n;
         }
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
                 f32x4 w = R.v[k];
                 if (a.in_stats) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[c] = fmaxf(fmaf(w[c], nsc[c], nnb[c]), 0.f);
+                    for (int c = 0; c < 4; ++c) w[c] = fmaxf((w[c] - nnb[c]) * nsc[c], 0.f);  // norm_apply_kernel's arithmetic, bit for bit
                 }
                 if (!((R.okmask >> k) & 1)) w = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;

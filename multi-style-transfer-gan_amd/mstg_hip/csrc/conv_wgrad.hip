@@ -769,7 +769,7 @@ static int wgrad_1x1_tile(int Cg, int Ch) {
 template <int MF, int NW>
 __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
                                                         long P, int Cg, int g_ctot, int g_coff, int Ch, int h_ctot, int h_coff,
-                                                        int with_bias, int P1) {
+                                                        int with_bias, int P1, const float* __restrict__ in_stats, int HW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lda = 16 * MF + 4, NF = (Ch + 15) / 16, ldb = 16 * NF + 4;
     float* As = smem;             // [P1][lda]
@@ -820,7 +820,15 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
             if (e < ea + eb) {
                 bool isa; int pr, q;
                 locate(e, isa, pr, q);
-                *reinterpret_cast<f32x4*>(&smem[isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q]) = ((okm >> k) & 1) ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 w = ((okm >> k) & 1) ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (in_stats && isa && ((okm >> k) & 1)) {
+                    // x is the RAW tensor in front of InstanceNorm + ReLU: normalise here, as norm_apply_kernel would have (the host
+                    // guarantees that a pixel run stays inside one image: HW % P1 == 0)
+                    const float* st = in_stats + ((size_t)(tile * P1 / HW) * g_ctot + g_coff + 4 * q) * 2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) w[c] = fmaxf((w[c] - st[2 * c]) * st[2 * c + 1], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(&smem[isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q]) = w;
             }
         }
         __syncthreads();
@@ -883,11 +891,11 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
 }
 
 template <int MF, int NW>
-static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st) {
+static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st, const float* in_stats = nullptr) {
     const int NF = cdiv(a.Ch, 16), P1 = wgrad_1x1_tile(a.Cg, a.Ch);
     const size_t lds = (size_t)P1 * ((16 * MF + 4) + (16 * NF + 4)) * sizeof(float);
     hipLaunchKernelGGL((wgrad_1x1_kernel<MF, NW>), dim3(S), dim3(256), lds, st, a.g, a.h, a.partial, P, a.Cg, a.g_ctot, a.g_coff, a.Ch,
-                       a.h_ctot, a.h_coff, a.with_bias, P1);
+                       a.h_ctot, a.h_coff, a.with_bias, P1, in_stats, a.hH * a.hW);
     MSTG_CHECK_LAUNCH("wgrad_1x1_kernel");
     return MSTG_OK;
 }
@@ -1216,8 +1224,40 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     return w > w_11 ? w : w_11;
 }
 
+static bool wgrad_norm_ok(const WGradArgs& a) {  // normalise-on-load exists in the 1x1 kernel, for pixel runs that stay inside one image
+    if (!wgrad_1x1_ok(a) || a.g_coff != 0) return false;
+    const W11Chunks c = wgrad_1x1_chunks(a);
+    for (int ig = 0; ig < c.ng; ++ig)
+        for (int ih = 0; ih < c.nh; ++ih) {
+            const WGradArgs b = wgrad_1x1_block(a, c, ig, ih);
+            if ((a.hH * a.hW) % wgrad_1x1_tile(b.Cg, b.Ch)) return false;
+        }
+    return true;
+}
+
+extern "C" int mstg_conv2d_wgrad_norm_supported(const mstg_conv_desc* d) {
+    if (check_desc(d) || d->transposed) return 0;
+    WGradArgs a{};
+    if (fill_wgrad_args(d, nullptr, nullptr, a)) return 0;
+    return wgrad_norm_ok(a) ? 1 : 0;
+}
+
+static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* dy, float* dw, float* dbias,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                  void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(d, x, nullptr, dy, dw, dbias, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mstg_conv2d_wgrad_norm(const mstg_conv_desc* d, const float* x_raw, const float* in_stats, const float* dy, float* dw,
+                                      float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!in_stats) return fail_arg(MSTG_E_BADARG, "conv_wgrad_norm: null statistics");
+    return conv2d_wgrad_impl(d, x_raw, in_stats, dy, dw, dbias, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* dy, float* dw, float* dbias,
+                             void* workspace, size_t workspace_bytes, void* stream) {
     if (int rc = check_desc(d)) return rc;
     if (!x || !dy || !dw || !workspace) return fail_arg(MSTG_E_BADARG, "conv_wgrad: null pointer");
     if (dbias && d->transposed)
@@ -1231,6 +1271,8 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
     // measured on MI355X: the tap-split kernel wins where a workgroup gets 32 units (16 taps x 2 column fragments: the
     // stride-2 / transposed 4x4 layers with 17..32 grid channels); the pixel-split kernel elsewhere
     const bool use_ts = a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch();
+    if (in_stats && (d->transposed || !wgrad_norm_ok(a)))
+        return fail_arg(MSTG_E_UNSUPPORTED, "conv_wgrad_norm: only the layers mstg_conv2d_wgrad_norm_supported() reports");
     if (wgrad_1x1_ok(a)) {
         if (workspace_bytes < wgrad_1x1_workspace(a)) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
         const long P = (long)a.N * a.hH * a.hW;
@@ -1242,7 +1284,7 @@ extern "C" int mstg_conv2d_wgrad(const mstg_conv_desc* d, const float* x, const 
                 const int Sb = wgrad_1x1_splits(b);
                 const int MF = cdiv(b.Cg, 16), NW = cdiv(cdiv(b.Ch, 16), 4);
                 int rc = MSTG_E_UNSUPPORTED;
-#define MSTG_W11(M_, N_) if (MF == M_ && NW == N_) rc = launch_wgrad_1x1<M_, N_>(b, P, Sb, st);
+#define MSTG_W11(M_, N_) if (MF == M_ && NW == N_) rc = launch_wgrad_1x1<M_, N_>(b, P, Sb, st, in_stats);
                 MSTG_W11(1, 1) MSTG_W11(1, 2) MSTG_W11(1, 3) MSTG_W11(2, 1) MSTG_W11(2, 2) MSTG_W11(2, 3) MSTG_W11(3, 1) MSTG_W11(3, 2)
                 MSTG_W11(3, 3) MSTG_W11(4, 1) MSTG_W11(4, 2) MSTG_W11(4, 3)
 #undef MSTG_W11

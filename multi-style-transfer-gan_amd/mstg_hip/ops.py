@@ -293,6 +293,78 @@ class ConvStatsFn(torch.autograd.Function):
         return ConvFn.backward(ctx, dy)
 
 
+def ms_fusion_supported(N, H, W, Cn) -> bool:
+    """True where the MultiScaleBlock's concat norm can be folded into the 1x1 fusion convolution (forward: normalise-on-load in
+    the persistent conv kernel; backward: normalise-on-load in the 1x1 weight-gradient kernel)."""
+    d = make_desc(N, H, W, Cn, H, W, Cn, 1, 1, 0, 1)
+    lib = _lib.load()
+    return bool(lib.mstg_conv2d_fwd_norm_supported(C.byref(d))) and bool(lib.mstg_conv2d_wgrad_norm_supported(C.byref(d)))
+
+
+class MSFusionFn(torch.autograd.Function):
+    """f = Conv1x1(ReLU(InstanceNorm2d(cat))) of the MultiScaleBlock (enhanced_generator.py:72-75, 83) without the normalised concat
+    ever being written: one statistics pass over the raw concat, then the fusion convolution normalises while it stages its tiles;
+    in the backward the 1x1 weight-gradient kernel does the same, and the norm's own backward works from the raw tensor as always.
+    Two tensor passes fewer per block than norm kernel + convolution, with the same arithmetic on every element."""
+
+    @staticmethod
+    def forward(ctx, cat, w, b):
+        lib = _lib.load()
+        cat, w = _req(cat, "fusion input"), _req(w, "fusion weight")
+        b = None if b is None else _req(b, "fusion bias")
+        N, H, W, Cn = cat.shape
+        Cout = w.shape[0]
+        stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=cat.device)
+        ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
+        _timed("norm_act_fwd", 0, 4 * cat.numel(), lambda: _lib.check(
+            lib.mstg_norm_stats(_p(cat), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
+        y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
+        d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
+        ws2 = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
+        fl, by = _conv_cost(d)
+        _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
+            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), None, _p(ws2), ws2.numel() * 4, _stream()),
+            "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
+        ctx.dims, ctx.has_bias, ctx.prefs = (N, H, W, Cn, Cout), b is not None, (w, b)
+        ctx.save_for_backward(cat, stats, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        N, H, W, Cn, Cout = ctx.dims
+        cat, stats, w = ctx.saved_tensors
+        dy = _req(dy, "fusion grad_output")
+        d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
+        dcat = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dz = torch.empty_like(cat)
+            conv_dgrad_raw(d, dy, w, dz)  # gradient w.r.t. the normalised concat
+            dcat = torch.empty_like(cat)
+            ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
+            _timed("norm_act_bwd", 0, 4 * cat.numel() * 5, lambda: _lib.check(
+                lib.mstg_norm_act_bwd(_p(cat), _p(stats), _p(dz), _p(dcat), N, H * W, Cn, ACT_RELU, 0, None, None, None, None, _p(ws),
+                                      ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
+        if ctx.needs_input_grad[1]:
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
+            gw = _grad_slot(ctx.prefs[0])
+            gb = _grad_slot(ctx.prefs[1]) if want_db else None
+            direct = gw is not None and (gb is not None or not want_db)
+            if not direct:
+                dw = torch.empty_like(w)
+                db = torch.empty(Cout, dtype=torch.float32, device=dy.device) if want_db else None
+            d.accumulate = 1 if direct else 0
+            out_w, out_b = (gw, gb) if direct else (dw, db)
+            wsw = _ws(lib.mstg_conv2d_wgrad_workspace_bytes(C.byref(d)), cat.device)
+            fl, by = _conv_cost(d)
+            _timed(_kernel_name(d, 2), fl, by, lambda: _lib.check(
+                lib.mstg_conv2d_wgrad_norm(C.byref(d), _p(cat), _p(stats), _p(dy), _p(out_w), _p(out_b), _p(wsw), wsw.numel() * 4, _stream()),
+                "mstg_conv2d_wgrad_norm"), _conv_detail("wgrad", d))
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = channel_sum(dy, N * H * W, Cout, 0, Cout)
+        return dcat, dw, db
+
+
 def conv2d_stats(x, w, b, k, stride=1, pad=0, dil=1, transposed=False):
     return ConvStatsFn.apply(x, w, b, (k, stride, pad, dil, int(transposed)))
 

@@ -122,3 +122,37 @@ def test_conv_epilogue_statistics(tr, N, H, W, Ci, Co):
     g2 = torch.autograd.grad((y2 * gy).sum(), t2)
     for a_, b_ in zip(g1, g2):
         assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("N,H,W,Cn", [(3, 16, 16, 16), (2, 32, 32, 32), (1, 64, 64, 64), (2, 128, 128, 16)])
+def test_ms_fusion_folded_norm_vs_chain(N, H, W, Cn):
+    """The concat's IN + ReLU folded into the 1x1 fusion convolution (MSFusionFn: normalise-on-load in conv_p32_kernel and in
+    wgrad_1x1_kernel) against norm kernel + convolution: the same arithmetic on every element, so everything is bit-identical."""
+    from mstg_hip import ops
+    assert ops.ms_fusion_supported(N, H, W, Cn)
+    cat = rnd((N, H, W, Cn), 31, 1.7) - 0.2
+    w, b = rnd((Cn, Cn, 1, 1), 32, Cn ** -0.5), rnd((Cn,), 33, 0.3)
+    dy = rnd((N, H, W, Cn), 34)
+    outs = []
+    for fused in (True, False):
+        t = [v.to(DEV).requires_grad_(True) for v in (cat, w, b)]
+        f = ops.MSFusionFn.apply(*t) if fused else ops.conv2d(ops.instnorm_act(t[0], ops.ACT_RELU), t[1], t[2], 1)
+        g = torch.autograd.grad((f * dy.to(DEV)).sum(), t)
+        outs.append((f.detach().cpu(), [v.cpu() for v in g]))
+    assert torch.equal(outs[0][0], outs[1][0]), rel_l2(outs[0][0], outs[1][0])
+    for name, a_, b_ in zip(("dcat", "dw", "db"), outs[0][1], outs[1][1]):
+        report(f"ms fusion N{N} {H}x{W} C{Cn} {name} vs chain", rel_l2(a_, b_), 1e-6)
+        assert torch.equal(a_, b_), name
+    # and against the oracle's arithmetic (torch fp32 on the CPU)
+    t = [v.clone().requires_grad_(True) for v in (cat, w, b)]
+    z = F.relu(F.instance_norm(t[0].permute(0, 3, 1, 2), eps=1e-5))
+    fr = F.conv2d(z, t[1], t[2]).permute(0, 2, 3, 1)
+    gr = torch.autograd.grad((fr * dy).sum(), t)
+    report(f"ms fusion N{N} {H}x{W} C{Cn} f vs torch", rel_l2(outs[0][0], fr.detach()), 2e-5)
+    for name, a_, b_ in zip(("dcat", "dw", "db"), outs[0][1], gr):
+        report(f"ms fusion N{N} {H}x{W} C{Cn} {name} vs torch", rel_l2(a_, b_), 1e-4)
+
+
+def test_ms_fusion_not_offered_when_a_pixel_run_would_cross_images():
+    from mstg_hip import ops
+    assert not ops.ms_fusion_supported(2, 6, 6, 16)  # 36 pixels per image, 256-pixel runs
