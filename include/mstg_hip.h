@@ -111,6 +111,8 @@ int mstg_norm_act_bwd(const float* x, const float* stats, const float* dy, float
 /* The two halves on their own, for a norm whose neighbours do the other half (mstg_window_attn_norm_*): statistics only
  * (stats[n][c] = {mean, rstd}, bit-identical to what mstg_norm_act_fwd stores), and the backward's apply pass given
  * sums[n][s][2][C]: rows that add up, per (image, channel), to sum(dy * act') and sum(dy * act' * x^) (InstanceNorm only). */
+int mstg_norm_apply_fwd(const float* x, const float* stats, const float* residual /*nullable*/, float* y, int N, int HW, int C, int act,
+                        void* stream);  /* y = act((x - mean) * rstd) [+ residual] with the statistics given */
 int mstg_norm_stats(const float* x, float* stats, int N, int HW, int C, void* workspace, size_t workspace_bytes, void* stream);
 int mstg_norm_bwd_apply(const float* x, const float* stats, const float* dy, const float* sums /* [N][sums_split][2][C] */,
                         int sums_split, float* dx, int N, int HW, int C, int act, void* stream);

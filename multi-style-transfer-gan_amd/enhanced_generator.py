@@ -79,7 +79,9 @@ class MultiScaleBlock(nn.Module):
         if (os.environ.get("MSTG_NORM_FUSION", "1") != "0" and conv.kernel_size == (1, 1) and conv.out_channels == cat.shape[3]
                 and ops.ms_fusion_supported(cat.shape[0], cat.shape[1], cat.shape[2], cat.shape[3])):
             # the concat's IN + ReLU folded into the fusion convolution: the normalised concat is never written
-            f = ops.MSFusionFn.apply(cat, conv.weight, conv.bias)
+            # ... and the fusion output's statistics come out of the convolution's epilogue: its norm is the apply pass alone
+            f, fstats = ops.MSFusionFn.apply(cat, conv.weight, conv.bias)
+            return ops.instnorm_apply(f, fstats, ACT_RELU, residual=xres)
         else:
             cat = ops.instnorm_act(cat, ACT_RELU)      # per-channel IN: one launch covers all four branches
             f = conv(cat, nhwc=True)

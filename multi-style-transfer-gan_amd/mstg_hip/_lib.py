@@ -56,6 +56,7 @@ SIGNATURES = {
     "mstg_window_attn_norm_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_norm_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mstg_window_attn_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_norm_apply_fwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_norm_stats": (_i, [_fp, _fp, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_norm_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_norm_sums_split": (_i, []),

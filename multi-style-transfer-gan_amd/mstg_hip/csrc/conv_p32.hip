@@ -45,7 +45,8 @@ struct P32Args {
     const float* wpk;   // [step][frag][lane][4]
     const float* bias;  // [16 * NF], zeros for an input gradient
     const float* in_stats;  // nullable [N][Cin][2] (mean, rstd): the source is normalised + ReLU'd while it is staged
-    float* partial;         // STATS kernels: [N][workgroups][2][16 * NF] sums / sums of squares of what the workgroup wrote (zeroed by the host)
+    float* partial;         // STATS kernels: [N][workgroups][2][16 * NF] sums / sums of squares of what the workgroup wrote; only the
+                            // (image, workgroup) pairs that meet are written -- and read
     int N, H, W, Cin, Ho, Wo, Cout, Gh, Gw, tiles_x, tiles_y, dbg;
 };
 
@@ -187,9 +188,15 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
     const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 4;  // bytes between this wave's consecutive rows
     P32Regs<NPF> R;
     int it = 0;
-    int t = p32_tile(it, blockIdx.x, G);
-    if (t < total_tiles) p32_fetch<NPF>(a, p, t, TH, tid, rel, vmask, R);
-    while (t < total_tiles) {
+    // STATS: a workgroup takes a CONTIGUOUS range of tiles, so that an image is covered by a few workgroups and the statistics
+    // finalize reads a few rows per image (with the strided order every workgroup touches every image: a row per pair, a memset and a
+    // finalize that cost what the statistics pass they replace costs); otherwise the strided, XCD-contiguous order
+    const int chunk = STATS ? (total_tiles + G - 1) / G : 0;
+    const int t_end = STATS ? min(total_tiles, ((int)blockIdx.x + 1) * chunk) : total_tiles;
+    auto tile_of = [&](int i) { return STATS ? (int)blockIdx.x * chunk + i : p32_tile(i, blockIdx.x, G); };
+    int t = tile_of(it);
+    if (t < t_end) p32_fetch<NPF>(a, p, t, TH, tid, rel, vmask, R);
+    while (t < t_end) {
         const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
         const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
         const int gy0 = ty * TH, gx0 = tx * P32_TW;
@@ -215,8 +222,8 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
                 *reinterpret_cast<f32x4*>(patch + (unsigned)(((256 * k + tid) >> sh) * p.pixstride + 16 * o)) = w;
             }
         __syncthreads();
-        const int tnext = p32_tile(it + 1, blockIdx.x, G);
-        if (tnext < total_tiles && !(a.dbg & 4)) p32_fetch<NPF>(a, p, tnext, TH, tid, rel, vmask, R);
+        const int tnext = tile_of(it + 1);
+        if (tnext < t_end && !(a.dbg & 4)) p32_fetch<NPF>(a, p, tnext, TH, tid, rel, vmask, R);
 
         for (int sg = 0; sg < nseg; ++sg) {
             const int4 ci = *reinterpret_cast<const int4*>(smem + 4 * P32_MAX_STEPS + 16 * sg);
@@ -305,12 +312,14 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
 
 // partial [N][G][2][CP] -> stats [N][C][2] = (mean, rstd); one workgroup per image, double accumulation, fixed order
 __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int G, int CP,
-                                                                int C, float count) {
+                                                                int C, float count, int ntile, int chunk) {
     __shared__ double red[256 * 2];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int per_c = 256 / CP, c = tid % CP, sub = tid / CP;  // CP in {16, 32, 64} -> 16 / 8 / 4 threads share a channel
+    // rows written for image n: the workgroups whose contiguous tile range [b * chunk, (b + 1) * chunk) meets the image's tiles
+    const int b_lo = (int)(((long)n * ntile) / chunk), b_hi = (int)((((long)n + 1) * ntile - 1) / chunk);
     double s1 = 0.0, s2 = 0.0;
-    for (int b = sub; b < G; b += per_c) {
+    for (int b = b_lo + sub; b <= b_hi && b < G; b += per_c) {
         const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
         s1 += (double)pp[c];
         s2 += (double)pp[CP + c];
@@ -920,13 +929,12 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
     { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < c_occ) c_occ = atoi(e); }  // experiments: leave room for the other stream
     long g_ = 256L * c_occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
-    if (out_stats && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)
-        return fail_arg(MSTG_E_LAUNCH, "conv_p32: clearing the statistics partials failed");
     hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32_kernel");
     if (out_stats) {
+        const int ntile = a.tiles_x * a.tiles_y;
         hipLaunchKernelGGL(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
-                           (float)((size_t)a.Ho * a.Wo));
+                           (float)((size_t)a.Ho * a.Wo), ntile, (int)((tiles + g_ - 1) / g_));
         MSTG_CHECK_LAUNCH("p32_norm_finalize_kernel");
     }
     return MSTG_OK;

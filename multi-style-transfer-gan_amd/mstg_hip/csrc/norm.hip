@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     const float cnt = batch ? (float)g.N * (float)g.HW : (float)g.HW;
     for (int c = tid; c < C; c += 256) {
         float t1 = 0.f, t2 = 0.f;
-        if (batch != 2) {
+        if (batch != 2 && batch != 3) {
             const int nb = batch ? 0 : n, ne = batch ? g.N : n + 1;
             for (int nn = nb; nn < ne; ++nn)
                 for (int s = 0; s < psplit; ++s) {  // psplit = g.split, or 1 when a producer's epilogue already summed the tensor
@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
             if (batch == 2) {
                 mean = running_mean[c];
                 rstd = rsqrtf(running_var[c] + NORM_EPS);
+            } else if (batch == 3) {  // InstanceNorm with the statistics already known (a producer's epilogue summed them)
+                mean = stats[((size_t)n * C + c) * 2];
+                rstd = stats[((size_t)n * C + c) * 2 + 1];
             } else {
                 const float K = (batch ? x : x + (size_t)n * g.HW * C)[c];
                 const float e1 = t1 / cnt;
@@ -146,11 +149,12 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
                     running_var[c] = 0.9f * running_var[c] + 0.1f * var * (cnt / fmaxf(cnt - 1.f, 1.f));
                 }
             }
-            if (sp == 0 && (!batch || n == 0)) {
+            if (batch != 3 && sp == 0 && (!batch || n == 0)) {
                 stats[((size_t)(batch ? 0 : n) * C + c) * 2] = mean;
                 stats[((size_t)(batch ? 0 : n) * C + c) * 2 + 1] = rstd;
             }
-            const float ga = batch ? gamma[c] : 1.f, be = batch ? beta[c] : 0.f;
+            const bool affine = batch == 1 || batch == 2;
+            const float ga = affine ? gamma[c] : 1.f, be = affine ? beta[c] : 0.f;
             sm[c] = rstd * ga;                 // y = (x - mean) * a + b
             sm[C + c] = be;
             sm[2 * C + c] = mean;
@@ -347,5 +351,19 @@ extern "C" int mstg_norm_bwd_apply(const float* x, const float* stats, const flo
     hipLaunchKernelGGL((norm_apply_kernel<true>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, dy,
                        nullptr, dx, const_cast<float*>(stats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums, g, act, 0, sums_split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
+    return MSTG_OK;
+}
+
+// Forward apply pass of InstanceNorm + activation (+ residual) with the statistics given (mstg_conv2d_fwd_norm's out_stats):
+// y = act((x - mean) * rstd) [+ residual]; one read (two with the residual), one write.
+extern "C" int mstg_norm_apply_fwd(const float* x, const float* stats, const float* residual, float* y, int N, int HW, int C, int act,
+                                   void* stream) {
+    if (int rc = norm_check(N, HW, C)) return rc;
+    if (!x || !stats || !y) return fail_arg(MSTG_E_BADARG, "norm_apply_fwd: null pointer");
+    if (act == MSTG_ACT_TANH) return fail_arg(MSTG_E_UNSUPPORTED, "norm_apply_fwd: tanh epilogue not supported");
+    const NormGeom g = norm_geom(N, HW, C);
+    hipLaunchKernelGGL((norm_apply_kernel<false>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, nullptr,
+                       residual, y, const_cast<float*>(stats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, act, 3, 0);
+    MSTG_CHECK_LAUNCH("norm_apply_kernel");
     return MSTG_OK;
 }

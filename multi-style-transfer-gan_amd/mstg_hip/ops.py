@@ -319,18 +319,20 @@ class MSFusionFn(torch.autograd.Function):
         _timed("norm_act_fwd", 0, 4 * cat.numel(), lambda: _lib.check(
             lib.mstg_norm_stats(_p(cat), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
+        ystats = torch.empty((N, Cout, 2), dtype=torch.float32, device=cat.device)  # (mean, rstd) of y from the epilogue
         d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
         ws2 = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
         fl, by = _conv_cost(d)
-        _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
-            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), None, _p(ws2), ws2.numel() * 4, _stream()),
+        _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(
+            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), _p(ystats), _p(ws2), ws2.numel() * 4, _stream()),
             "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
         ctx.dims, ctx.has_bias, ctx.prefs = (N, H, W, Cn, Cout), b is not None, (w, b)
         ctx.save_for_backward(cat, stats, w)
-        return y
+        ctx.mark_non_differentiable(ystats)
+        return y, ystats
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dystats):
         lib = _lib.load()
         N, H, W, Cn, Cout = ctx.dims
         cat, stats, w = ctx.saved_tensors
@@ -494,6 +496,33 @@ class InstNormActFn(torch.autograd.Function):
 
 def instnorm_act(x, act=ACT_RELU, residual=None):
     return InstNormActFn.apply(x, residual, act)
+
+
+class InstNormApplyFn(torch.autograd.Function):
+    """y = act(InstanceNorm2d(x)) [+ residual] with the statistics given (a producer's epilogue summed them): the forward is the apply
+    pass alone; the backward is InstNormActFn's."""
+
+    @staticmethod
+    def forward(ctx, x, stats, residual, act):
+        lib = _lib.load()
+        x, stats = _req(x, "norm input"), _req(stats, "norm statistics")
+        residual = None if residual is None else _req(residual, "norm residual")
+        N, H, W, Cn = x.shape
+        y = torch.empty_like(x)
+        _timed("norm_act_fwd", 0, 4 * x.numel() * (2 if residual is None else 3), lambda: _lib.check(
+            lib.mstg_norm_apply_fwd(_p(x), _p(stats), _p(residual), _p(y), N, H * W, Cn, act, _stream()), "mstg_norm_apply_fwd"))
+        ctx.act, ctx.has_res = act, residual is not None
+        ctx.save_for_backward(x, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dres, _ = InstNormActFn.backward(ctx, dy)
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None
+
+
+def instnorm_apply(x, stats, act=ACT_RELU, residual=None):
+    return InstNormApplyFn.apply(x, stats, residual, act)
 
 
 class BatchNormActFn(torch.autograd.Function):

@@ -136,7 +136,7 @@ def test_ms_fusion_folded_norm_vs_chain(N, H, W, Cn):
     outs = []
     for fused in (True, False):
         t = [v.to(DEV).requires_grad_(True) for v in (cat, w, b)]
-        f = ops.MSFusionFn.apply(*t) if fused else ops.conv2d(ops.instnorm_act(t[0], ops.ACT_RELU), t[1], t[2], 1)
+        f = ops.MSFusionFn.apply(*t)[0] if fused else ops.conv2d(ops.instnorm_act(t[0], ops.ACT_RELU), t[1], t[2], 1)
         g = torch.autograd.grad((f * dy.to(DEV)).sum(), t)
         outs.append((f.detach().cpu(), [v.cpu() for v in g]))
     assert torch.equal(outs[0][0], outs[1][0]), rel_l2(outs[0][0], outs[1][0])
@@ -156,3 +156,30 @@ def test_ms_fusion_folded_norm_vs_chain(N, H, W, Cn):
 def test_ms_fusion_not_offered_when_a_pixel_run_would_cross_images():
     from mstg_hip import ops
     assert not ops.ms_fusion_supported(2, 6, 6, 16)  # 36 pixels per image, 256-pixel runs
+
+
+@pytest.mark.parametrize("N,H,W,Cn", [(3, 32, 32, 16), (2, 64, 64, 32)])
+def test_ms_fusion_output_statistics_and_apply(N, H, W, Cn):
+    """Fusion convolution with epilogue statistics + apply-only norm against conv + full norm: the epilogue's (mean, rstd) differ
+    from the pivoted two-pass ones by fp32 rounding, so outputs agree to ~1e-6 rather than bit for bit."""
+    from mstg_hip import ops
+    cat = rnd((N, H, W, Cn), 41, 1.3)
+    w, b = rnd((Cn, Cn, 1, 1), 42, Cn ** -0.5), rnd((Cn,), 43, 0.3)
+    res = rnd((N, H, W, Cn), 44)
+    dy = rnd((N, H, W, Cn), 45)
+    outs = []
+    for fused in (True, False):
+        t = [v.to(DEV).requires_grad_(True) for v in (cat, w, b, res)]
+        if fused:
+            f, fs = ops.MSFusionFn.apply(t[0], t[1], t[2])
+            h = ops.instnorm_apply(f, fs, ops.ACT_RELU, residual=t[3])
+        else:
+            h = ops.instnorm_act(ops.conv2d(ops.instnorm_act(t[0], ops.ACT_RELU), t[1], t[2], 1), ops.ACT_RELU, residual=t[3])
+        g = torch.autograd.grad((h * dy.to(DEV)).sum(), t)
+        outs.append((h.detach().cpu(), [v.cpu() for v in g]))
+    report(f"fusion+stats N{N} {H}x{W} C{Cn} h vs chain", rel_l2(outs[0][0], outs[1][0]), 2e-6)
+    for name, a_, b_ in zip(("dcat", "dw", "db", "dres"), outs[0][1], outs[1][1]):
+        if name == "db":  # the bias of a convolution that feeds an InstanceNorm: its exact gradient is zero, both are rounding noise
+            assert float(a_.abs().max()) <= 1e-3 and float(b_.abs().max()) <= 1e-3
+            continue
+        report(f"fusion+stats N{N} {H}x{W} C{Cn} {name} vs chain", rel_l2(a_, b_), 2e-5)
