@@ -33,7 +33,7 @@ constexpr int F16_MAX_GRID = 1024;  // persistent workgroups: 256 CUs x at most 
 constexpr int F16_TABLE_BYTES = (64 + F16_MAX_SEG) * 16;  // K-step table + segment table at the start of the kernel's LDS
 
 // how the pack kernel fills one half (4 k-elements) of a lane group
-enum : int8_t { PK_ZERO = 0, PK_CONV = 1, PK_CONVT = 2, PK_MS_CENTER = 3, PK_MS_RING1 = 4 /* +0,1,2 = branches 2,3,4 */ };
+enum : int8_t { PK_ZERO = 0, PK_CONV = 1, PK_CONVT = 2, PK_MS_CENTER = 3, PK_MS_RING1 = 4 /* +0,1,2 = branches 2,3,4 */, PK_DPACK = 7 };
 struct PackHalf { int8_t mode, ky, kx; int8_t pad; int16_t cb; };
 struct PackTable {
     PackHalf h[F16_MAX_STEPS][4][2];
@@ -59,6 +59,7 @@ struct F16Plan {
     int oy0, ox0;                     // patch origin = tile origin * stride + (oy0, ox0)
     int stride, up;                   // compute-grid stride in the source; up = 1: outputs at 2*y+oy, 2*x+ox
     int NF, TH;
+    int tstep, dpack;                 // tile advance in compute-grid columns (16; 13 with dpack), <= 4 output channels as 4 shifts x 4 channels
 };
 
 struct F16ConvArgs {
@@ -104,11 +105,14 @@ __global__ void f16_pack_kernel(PackTable t, PackSrc s, int nwfrag, int NF, h16*
         const PackHalf ph = t.h[step][g][hf];
         const int co = 16 * f + m, ci = ph.cb + jj;
         float v = 0.f;
-        if (ph.mode != PK_ZERO && co < s.Cout && ci < s.Cin && ph.cb >= 0) {
+        if (ph.mode != PK_ZERO && (co < s.Cout || ph.mode == PK_DPACK) && ci < s.Cin && ph.cb >= 0) {
             if (ph.mode == PK_CONV) {
                 v = s.w[0][((size_t)(co * s.Cin + ci) * s.KH + ph.ky) * s.KW + ph.kx];
             } else if (ph.mode == PK_CONVT) {
                 v = s.w[0][((size_t)(ci * s.Cout + co) * s.KH + ph.ky) * s.KW + ph.kx];
+            } else if (ph.mode == PK_DPACK) {  // row m = 4 * delta + c carries the real tap kx = 4 j + 3 - delta of output channel c
+                const int delta = m >> 2, c = m & 3, kx = 4 * ph.kx + 3 - delta;
+                v = (f == 0 && c < s.Cout && kx >= 0 && kx < s.KW) ? s.w[0][((size_t)(c * s.Cin + ci) * s.KH + ph.ky) * s.KW + kx] : 0.f;
             } else {
                 const int br = co / s.c4, cb = co - br * s.c4;  // branch of this output channel
                 if (ph.mode == PK_MS_CENTER) {
@@ -186,7 +190,7 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
     const int ntile = a.tiles_x * a.tiles_y;
     const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
     const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
-    const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * F16_TW * p.stride + p.ox0;
+    const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * p.tstep * p.stride + p.ox0;
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + p.PH <= a.H && sx0 + p.PW <= a.W;  // uniform
     if (SRC == 0) {
         const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 2;
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
     (void)pixstride;
     f32x4 b4[NF];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) b4[f] = *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
+    for (int f = 0; f < NF; ++f) b4[f] = (DST == 1 && p.dpack) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
 
     // statistics of what this workgroup writes, per channel: kept in registers across the tiles of one image and flushed to
     // partial[image][workgroup] when the image changes (the buffer is zeroed by the host: not every workgroup sees every image)
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
     while (t < total_tiles) {
         const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
         const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
-        const int gy0 = ty * TH, gx0 = tx * F16_TW;
+        const int gy0 = ty * TH, gx0 = tx * p.tstep;
         if (want_stats && n != cur_n) {
             if (cur_n >= 0) flush_stats(cur_n);
             cur_n = n;
@@ -467,6 +471,30 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
                         for (int q = 0; q < 4; ++q) hv[q] = (h16)v[q];
                         *reinterpret_cast<h16x4*>(ybase + r * out_row + out_off0 + 32 * f) = hv;
                     }
+                continue;
+            }
+            if (DST == 1 && p.dpack) {
+                // 4-shift packing: accumulator row 4 delta + c of column p is a partial sum of output column p + delta.
+                // y[q][c] = sum_delta D[delta][q - delta] through LDS (the patch is dead once every wave is past its K-steps)
+                __syncthreads();
+                float* comb = reinterpret_cast<float*>(patch) + wv * (256 * RPW);  // [row][delta][p][4]
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) *reinterpret_cast<f32x4*>(&comb[((r * 4 + g) * 16 + nl) * 4]) = acc[r][0];
+                __syncthreads();
+                if (g < RPW && nl < 13 && !(a.dbg & 2)) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(a.bias);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) v += *reinterpret_cast<const f32x4*>(&comb[((g * 4 + d) * 16 + nl + 3 - d) * 4]);
+                    const int gy = gy0 + RPW * wv + g, gx = gx0 + nl;
+                    if (gy < a.Gh && gx < a.Gw) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (q < a.Cout) {
+                                const float o = a.act == MSTG_ACT_TANH ? 1.f - 2.f * __frcp_rn(__expf(2.f * v[q]) + 1.f) : v[q];
+                                a.y[(((size_t)n * a.Cout + q) * a.Ho + gy) * a.Wo + gx] = (h16)o;
+                            }
+                    }
+                }
                 continue;
             }
 #pragma unroll
@@ -605,6 +633,19 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
         p.stride = d->stride;
         halo_lo = -d->pad;
         halo_hi = d->dil * (K - 1) - d->pad;
+        const char* e_dp = getenv("MSTG_F16_DPACK");
+        p.dpack = d->dst_nchw && !image_src && d->stride == 1 && d->dil == 1 && d->Cout <= 4 && K >= 3 && K <= 7 && !(e_dp && e_dp[0] == '0');
+        if (p.dpack) {  // rows of the MFMA tile = 4 column shifts x 4 channels: a packed tap (ky, j) reads patch column p + 4 j + 3
+            const int tapsx = (K + 3) / 4;
+            for (int ky = 0; ky < K; ++ky)
+                for (int j = 0; j < tapsx; ++j)
+                    for (int gi = 0; gi < ngrp; ++gi) {
+                        GroupList::G& g = gl[0].g[gl[0].n++];
+                        g.dy = ky; g.dx = 4 * j + 3; g.cb = 8 * gi; g.fm = 0x1;
+                        g.h[0] = PackHalf{PK_DPACK, (int8_t)ky, (int8_t)j, 0, (int16_t)(8 * gi)};
+                        g.h[1] = PackHalf{PK_DPACK, (int8_t)ky, (int8_t)j, 0, (int16_t)(8 * gi + 4)};
+                    }
+        } else
         for (int ky = 0; ky < K; ++ky) {
             if (image_src) {
                 extra_w = 1;
@@ -625,7 +666,7 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
             }
             if (gl[0].n > F16_MAX_STEPS * 4 - 16) break;
         }
-        if ((image_src ? K * ((K + 1) / 2) : K * K * ngrp) > F16_MAX_STEPS * 4) { delete[] gl; return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: too many taps x channels"); }
+        if (!p.dpack && (image_src ? K * ((K + 1) / 2) : K * K * ngrp) > F16_MAX_STEPS * 4) { delete[] gl; return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: too many taps x channels"); }
     } else if (d->kind == 1) {  // ConvTranspose2d k4 s2 p1: class (py, px) reads source rows y + {-1,0} (py = 0) or y + {0,1} (py = 1)
         if (K != 4 || d->stride != 2 || d->pad != 1 || d->Ho != 2 * d->H || d->Wo != 2 * d->W) { delete[] gl; return fail_arg(MSTG_E_UNSUPPORTED, "f16 convT: only k4 s2 p1"); }
         p.up = 1;
@@ -687,6 +728,12 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
     const int ext0 = halo_hi - halo_lo;  // rows / cols beyond (T - 1) * stride + 1
     p.PW = (F16_TW - 1) * p.stride + 1 + ext0 + extra_w;  // PH / TH are chosen below, once the filter size is known
     p.oy0 = p.ox0 = halo_lo;
+    p.tstep = F16_TW;
+    if (p.dpack) {  // 16 accumulator columns start 3 pixels left of the tile's 13 output columns
+        p.PW = 15 + 4 * ((K + 3) / 4);
+        p.ox0 = halo_lo - 3;
+        p.tstep = 13;
+    }
     // ---- four groups per K-step ---------------------------------------------------------------------------------------------
     int s = 0;
     for (int cls = 0; cls < p.ncls; ++cls) {
@@ -762,7 +809,7 @@ static int build_plan(const mstg_f16_conv_desc* d, F16Plan& p, PackTable& pt) {
     // one output fragment: 32-row tiles (eight rows per wave) halve everything a tile does once per step / per tile and cut the
     // halo share; taken when two workgroups per CU still fit and the image is tall enough to have whole tiles
     const int gh_plan = d->kind == 1 ? d->H : d->Ho;
-    if (p.NF == 1 && th_max >= 32 && gh_plan >= 32 && wb + patch_bytes_of(32) <= 78 * 1024) { TH = 32; p.wlds = 1; }
+    if (p.NF == 1 && !p.dpack && th_max >= 32 && gh_plan >= 32 && wb + patch_bytes_of(32) <= 78 * 1024) { TH = 32; p.wlds = 1; }
     else if (wb + patch_bytes_of(16) <= 78 * 1024) { TH = 16; p.wlds = 1; }
     else if (wb + patch_bytes_of(8) <= 78 * 1024) { TH = 8; p.wlds = 1; }
     else if (wb + patch_bytes_of(16) <= 156 * 1024) { TH = 16; p.wlds = 1; }
@@ -886,7 +933,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     a.Gh = p.up ? d->H : d->Ho;
     a.Gw = p.up ? d->W : d->Wo;
     a.tiles_y = cdiv(a.Gh, p.TH);
-    a.tiles_x = cdiv(a.Gw, F16_TW);
+    a.tiles_x = cdiv(a.Gw, p.tstep);
     a.act = d->act;
     { const char* e = getenv("MSTG_F16_DBG"); a.dbg = e ? atoi(e) : 0; }
     const long tiles = (long)a.N * a.tiles_x * a.tiles_y;
