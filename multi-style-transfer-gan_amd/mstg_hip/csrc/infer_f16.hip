@@ -537,6 +537,142 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, cons
     if (want_stats && cur_n >= 0) flush_stats(cur_n);
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// 1x1 convolutions without the LDS patch.  For a 1x1 filter the MFMA's B fragment IS the memory layout: lane (pixel n, group g)
+// needs channels 8g .. 8g+7 of its pixel = 16 contiguous bytes of the NHWC tensor.  conv_f16_kernel spends ~45 % of such a
+// layer in per-tile fixed costs (LDS commit, table reads, pipeline prologue, barriers) for ONE K-step per tile; here a wave loads
+// its fragments straight from global memory (next tile's in flight behind the current tile's MFMAs), normalises them in registers,
+// keeps the whole filter in registers and only touches LDS to reduce the statistics.  Same tiles, same tile order, same partial rows
+// as conv_f16_kernel, so the statistics stay batch-independent bit for bit.
+// -------------------------------------------------------------------------------------------------------------------------
+template <int NF, int KS>  // output fragments (Cout / 16), K-steps (ceil(Cin / 32))
+__global__ __launch_bounds__(256) void conv1x1_f16_kernel(const F16ConvArgs a, const F16Plan p) {
+    __shared__ float red[8 * 16 * NF];
+    constexpr int RPW = 4, TH = 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nl = lane & 15, g = lane >> 4;
+    const int ntile = a.tiles_x * a.tiles_y, total_tiles = a.N * ntile, G = gridDim.x;
+    const bool want_stats = a.partial != nullptr, norm = a.in_stats != nullptr;
+    h16x8 af[KS][NF];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) af[s][f] = reinterpret_cast<const h16x8*>(a.wpk)[(size_t)(s * NF + f) * 64 + lane];
+    f32x4 b4[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) b4[f] = *reinterpret_cast<const f32x4*>(a.bias + 16 * f + 4 * g);
+    bool chan_ok[KS];  // this lane's 8-channel group of step s exists (Cin = 16 fills only groups 0 and 1 of the single step)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) chan_ok[s] = 8 * (4 * s + g) < a.Cin;
+    float ssum[NF][4], ssq[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ssum[f][q] = ssq[f][q] = 0.f;
+    auto flush_stats = [&](int n_img) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float s1 = row16_sum_f(ssum[f][q]), s2 = row16_sum_f(ssq[f][q]);
+                if (nl == 0) {
+                    red[(wv * 2 + 0) * 16 * NF + 16 * f + 4 * g + q] = s1;
+                    red[(wv * 2 + 1) * 16 * NF + 16 * f + 4 * g + q] = s2;
+                }
+                ssum[f][q] = ssq[f][q] = 0.f;
+            }
+        __syncthreads();
+        if (tid < 2 * 16 * NF)
+            a.partial[((size_t)n_img * G + blockIdx.x) * 2 * 16 * NF + tid] = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
+        __syncthreads();
+    };
+    struct Frag { h16x8 v[RPW][KS]; unsigned ok; };
+    auto fetch = [&](int t, Frag& F) {
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+        const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 2;
+        F.ok = 0;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int gy = ty * TH + RPW * wv + r, gx = tx * F16_TW + nl;
+            const bool in = gy < a.H && gx < a.W;
+            F.ok |= (unsigned)in << r;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bool ld = in && chan_ok[s];
+                F.v[r][s] = *reinterpret_cast<const h16x8*>(img + (ld ? ((size_t)(gy * a.W + gx) * a.Cin + 8 * (4 * s + g)) * 2 : 0));
+                if (!ld) F.v[r][s] = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+    };
+    Frag F;
+    int it = 0, cur_n = -1, cur_in = -1;
+    float sc[KS][8], nb[KS][8];  // (x - mean) * rstd = x * sc + nb for this lane's channels of the current image
+    int t = persistent_tile(it, blockIdx.x, G);
+    if (t < total_tiles) fetch(t, F);
+    while (t < total_tiles) {
+        const int n = ntile == 1 ? t : (int)__umulhi((unsigned)t, p.m_ntile), tt = t - n * ntile;
+        const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
+        if (want_stats && n != cur_n) {
+            if (cur_n >= 0) flush_stats(cur_n);
+            cur_n = n;
+        }
+        if (norm && n != cur_in) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float* st = a.in_stats + ((size_t)n * a.Cin + (chan_ok[s] ? 8 * (4 * s + g) : 0)) * 2;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { sc[s][c] = st[2 * c + 1]; nb[s][c] = -st[2 * c] * st[2 * c + 1]; }
+            }
+            cur_in = n;
+        }
+        // this tile's operands out of the prefetch registers (normalised), then the next tile's loads go out
+        h16x8 bf[RPW][KS];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                h16x8 w = F.v[r][s];
+                if (norm) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[c] = (h16)fmaxf(fmaf((float)w[c], sc[s][c], nb[s][c]), 0.f);
+                    if (!((F.ok >> r) & 1) || !chan_ok[s]) w = h16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+                bf[r][s] = w;
+            }
+        const unsigned okr = F.ok;
+        const int tnext = persistent_tile(it + 1, blockIdx.x, G);
+        if (tnext < total_tiles) fetch(tnext, F);
+        f32x4 acc[RPW][NF];
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) acc[r][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s][f], bf[r][s], s == 0 ? b4[f] : acc[r][f], 0, 0, 0);
+        char* yimg = reinterpret_cast<char*>(a.y) + (size_t)n * a.Ho * a.Wo * a.Cout * 2;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            if (!((okr >> r) & 1)) continue;
+            const int gy = ty * TH + RPW * wv + r, gx = tx * F16_TW + nl;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const f32x4 v = acc[r][f];
+                if (want_stats) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ssum[f][q] += v[q]; ssq[f][q] += v[q] * v[q]; }
+                }
+                h16x4 hv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hv[q] = (h16)v[q];
+                *reinterpret_cast<h16x4*>(yimg + ((size_t)(gy * a.Wo + gx) * a.Cout + 16 * f + 4 * g) * 2) = hv;
+            }
+        }
+        ++it;
+        t = tnext;
+    }
+    if (want_stats && cur_n >= 0) flush_stats(cur_n);
+}
+
 // partial [N][tiles][2][CP] -> stats [N][C][2] = (mean, rstd); one workgroup per image, double accumulation, fixed order
 __global__ __launch_bounds__(256) void f16_norm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats,
                                                                 int tiles, int CP, int C, float count) {
@@ -957,6 +1093,46 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     const long grid = tiles;
     int launched = 0;
     hipStream_t st = (hipStream_t)stream;
+    {   // 1x1: fragments straight from global memory, no LDS patch (conv1x1_f16_kernel)
+        const char* e = getenv("MSTG_F16_DIRECT");
+        const bool direct = d->kind == 0 && d->K == 1 && d->stride == 1 && !d->src_nchw_f32 && !d->dst_nchw && d->act == MSTG_ACT_NONE &&
+                            (d->Cout & 15) == 0 && p.TH == 16 && !(e && e[0] == '0');
+        if (direct) {
+            const int KS = (d->Cin + 31) / 32;
+            auto go = [&](auto kern) -> int {
+                static int occ = 0;
+                if (!occ) {
+                    int nb = 1;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 256, 0) != hipSuccess || nb < 1) nb = 1;
+                    occ = nb > 4 ? 4 : nb;
+                }
+                long g_ = 256L * occ;
+                if (g_ > grid) g_ = (grid + 7) & ~7L;
+                if (a.partial && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * p.NF * sizeof(float), st) != hipSuccess)
+                    return fail_arg(MSTG_E_LAUNCH, "f16 conv: clearing the statistics partials failed");
+                launched = (int)g_;
+                hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), 0, st, a, p);
+                MSTG_CHECK_LAUNCH("conv1x1_f16_kernel");
+                return MSTG_OK;
+            };
+            int rc = MSTG_E_UNSUPPORTED;
+            if (p.NF == 1 && KS == 1) rc = go(conv1x1_f16_kernel<1, 1>);
+            else if (p.NF == 2 && KS == 1) rc = go(conv1x1_f16_kernel<2, 1>);
+            else if (p.NF == 4 && KS == 2) rc = go(conv1x1_f16_kernel<4, 2>);
+            else if (p.NF == 4 && KS == 1) rc = go(conv1x1_f16_kernel<4, 1>);
+            else if (p.NF == 2 && KS == 2) rc = go(conv1x1_f16_kernel<2, 2>);
+            else if (p.NF == 1 && KS == 2) rc = go(conv1x1_f16_kernel<1, 2>);
+            if (rc != MSTG_E_UNSUPPORTED) {
+                if (rc) return rc;
+                if (out_stats) {
+                    hipLaunchKernelGGL(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, launched,
+                                       16 * p.NF, d->Cout, (float)((size_t)d->Ho * d->Wo));
+                    MSTG_CHECK_LAUNCH("f16_norm_finalize_kernel");
+                }
+                return MSTG_OK;
+            }
+        }
+    }
     const int src = d->src_nchw_f32 ? 1 : 0, dst = d->dst_nchw ? 1 : 0;
     int lrc;
     if (p.TH == 32) {
