@@ -81,6 +81,8 @@ class _PackedConv:
         flops = 2.0 * pix * self.Cin * cout_eff * taps
         nbytes = x.numel() * x.element_size() + y.numel() * 2
         name = {0: "conv_f16_kernel", 1: "conv_f16_kernel<convT>", 2: "conv_f16_kernel<msblock>"}[self.kind]
+        if self.kind == 0 and self.K == 1 and self.stride == 1 and not self.src_nchw_f32 and not self.dst_nchw:
+            name = "conv1x1_f16_kernel"  # the LDS-free streaming variant (unless MSTG_F16_DIRECT=0)
         _timed(name, flops, nbytes, lambda: _lib.check(
             lib.mstg_f16_conv_fwd(C.byref(d), _p(self.blob), _p(x), _p(in_stats), _p(y), _p(stats), _p(ws), wsb, _stream()),
             "mstg_f16_conv_fwd"), f"k{self.kind} N{N} {H}x{W} {self.Cin}->{self.Cout} k{self.K} s{self.stride}")
