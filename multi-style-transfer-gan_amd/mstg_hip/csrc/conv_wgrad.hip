@@ -428,6 +428,14 @@ __global__ __launch_bounds__(256, 3) void wgrad_ts_kernel(const WGradArgs a, con
 // DESIGN.md) runs behind the arithmetic instead of in front of it.  Same LDS layouts, same unit dealing, same partial-slab
 // layout and reduce kernel as wgrad_ts_kernel.
 // =====================================================================================================================
+#ifndef WP_CKP
+#define WP_CKP 24
+#endif
+#ifndef WP_BNP
+#define WP_BNP 48
+#endif
+// LDS strides (floats) of a patch pixel / a grid-tile pixel: the b32 operand reads of a half-wave touch 16 consecutive floats at two
+// pixels, conflict-free when the two pixels sit 16 banks apart: 2 * 24 = 48 = 16 (mod 32) for the stride-2 patch, 48 for the tile
 constexpr int WP_TH = 4, WP_NFHT = 2, WP_UW = 8, WP_NG = 6, WP_NH = 2;  // 10 x 34 x 4 patch quads = 5.3 per thread; 64 x 8 tile quads = 2
 
 struct WpRegs {
@@ -468,8 +476,8 @@ __device__ __forceinline__ void wp_fetch(const WGradArgs& a, int tile, int tid, 
 
 __global__ __launch_bounds__(256, 3) void wgrad_p32_kernel(const WGradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TH = WP_TH, NFHT = WP_NFHT, UW = WP_UW, BNP = 16 * NFHT + 4;
-    const int ckp = a.ckp;
+    constexpr int TH = WP_TH, NFHT = WP_NFHT, UW = WP_UW, BNP = WP_BNP;
+    constexpr int ckp = WP_CKP;
     float* patch = smem;                                // [PH][PW][ckp]
     float* ht = smem + ((a.PH * a.PW * ckp + 3) & ~3);  // [TH*16][BNP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -1089,7 +1097,7 @@ struct WpPlan { int S, ny; size_t lds, ws_bytes; };
 static WpPlan wp_plan(const WGradArgs& a) {  // a: after plan_ts (tiles for TH = 4)
     WpPlan p;
     p.ny = a.n_gchunks * (a.Ch / (16 * WP_NFHT));
-    p.lds = ((size_t)((a.PH * a.PW * a.ckp + 3) & ~3) + (size_t)WP_TH * 16 * (16 * WP_NFHT + 4)) * sizeof(float);
+    p.lds = ((size_t)((a.PH * a.PW * WP_CKP + 3) & ~3) + (size_t)WP_TH * 16 * WP_BNP) * sizeof(float);
     const size_t slab = ((size_t)a.T * a.Cg * a.Ch + a.Ch) * sizeof(float);
     int S = 1024 / p.ny;  // at most four workgroups per CU; the launch clamps to what the kernel's registers / LDS really allow
     while (S > 128 && (size_t)S * slab > ((size_t)48 << 20)) S >>= 1;
