@@ -192,16 +192,24 @@ def cpu_baseline(args):
     sweep.append({"threads": best["threads"], "batch": 4, "size": probe, "images_per_sec": round(imgs / dt, 4)})
     print(f"[bench] cpu baseline probe {probe}x{probe}: batch 4, {best['threads']} threads {imgs / dt:.3f} images/s", file=sys.stderr, flush=True)
     fn, imgs = workload(1, size)
-    dt = timed(fn, warm=False)
+    fn()  # one warm-up pass, then >= 3 timed passes bounded to ~20 s; `value` is their median
+    passes, t_all = [], time.perf_counter()
+    while len(passes) < 3 or (len(passes) < 5 and time.perf_counter() - t_all < 10.0):
+        t0 = time.perf_counter()
+        fn()
+        passes.append(time.perf_counter() - t0)
+    dt = sorted(passes)[len(passes) // 2]
     value = imgs / dt
-    print(f"[bench] cpu baseline {size}x{size}: {best['threads']} threads {value:.3f} images/s", file=sys.stderr, flush=True)
+    print(f"[bench] cpu baseline {size}x{size}: {best['threads']} threads {value:.3f} images/s (median of {len(passes)} passes)",
+          file=sys.stderr, flush=True)
     one = next(r for r in sweep if r["threads"] == 1)
     torch.set_num_threads(ncpu)
     what = {"train": "oracle train step", "fwd": "oracle generator forward", "fwdbwd": "oracle generator forward+backward"}[kind]
     return {"value": round(value, 4), "unit": "images/sec", "cores": best["threads"], "kind": "port",
             "one_thread_probe_value": one["images_per_sec"], "host_cpus": os.cpu_count(), "usable_cpus": usable_cpus(), "sweep": sweep,
-            "sample": f"{what}, channels={C}, fp32: `value` = one pass at {size}x{size}, batch 1, {best['threads']} threads (the best of the "
-                      f"sweep); sweep points are single passes at {probe}x{probe}"}
+            "passes_sec": [round(t, 4) for t in passes],
+            "sample": f"{what}, channels={C}, fp32: `value` = median of {len(passes)} timed passes after one warm-up pass at {size}x{size}, "
+                      f"batch 1, {best['threads']} threads (the best of the sweep); sweep points are single passes at {probe}x{probe}"}
 
 
 def pmc_traffic(sym: str, args):
@@ -212,7 +220,7 @@ def pmc_traffic(sym: str, args):
     default = (args.config == 3 and args.batch == 32 and args.size == 256 and args.channels == 16 and not args.style_loss)
     if not default:
         return None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         if os.path.exists(path):
             t = json.load(open(path)).get(sym)
@@ -331,49 +339,56 @@ def main():
     roofline = None
     if not args.no_roofline:
         # EVERY rank runs the instrumented step (it contains the two gradient all-reduces); only rank 0 reports
-        ops.KernelTimer.enabled, ops.KernelTimer.records = True, []
+        ops.KernelTimer.start()
         step()
         torch.cuda.synchronize()
-        ops.KernelTimer.enabled = False
+        ops.KernelTimer.stop()
     if not args.no_roofline and dp.rank() == 0:
-        table = ops.KernelTimer.summary()
+        table = ops.KernelTimer.summary()              # per KERNEL symbol (what rocprofv3 --kernel-trace --stats ranks)
+        calls = ops.KernelTimer.summary(by_call=True)  # per C-ABI call (an op; may launch several kernels)
         total_ms = sum(r["ms"] for r in table.values())
+        peak_mfma = PEAK_F16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_F32_MFMA_TFLOPS
+
+        def against_roofs(r):
+            """(bound, achieved, unit, peak, frac) of algorithmic work r over its measured time, on the roof that bounds it."""
+            sec = r["ms"] / 1e3
+            t_mfma, t_hbm = r["flops"] / (peak_mfma * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
+            if t_mfma >= t_hbm and r["flops"] > 0:
+                ach = r["flops"] / sec / 1e12
+                return "mfma", round(ach, 3), "TFLOP/s", peak_mfma, round(ach / peak_mfma, 4)
+            ach = r["bytes"] / sec / 1e9
+            return "hbm", round(ach, 1), "GB/s", PEAK_HBM_GBS, round(ach / PEAK_HBM_GBS, 4)
+
         if args.kernel_table:
             for sym, r in sorted(ops.KernelTimer.summary(detail=True).items(), key=lambda kv: -kv[1]["ms"])[:200]:
                 print(f"[kernels] {sym:72s} launches {r['launches']:5d}  {r['ms']:9.3f} ms  {100 * r['ms'] / total_ms:5.1f}%  "
                       f"{r['flops'] / r['ms'] / 1e9 if r['ms'] else 0:8.2f} TFLOP/s  {r['bytes'] / r['ms'] / 1e6 if r['ms'] else 0:9.1f} GB/s",
                       file=sys.stderr)
-        # the timer brackets C-ABI calls; a call that launches two kernels cannot be attributed per kernel, so the dominant KERNEL
-        # is taken among the single-kernel calls (their names are the symbols rocprofv3 reports); the others stay in --kernel-table
-        sym, r = max(((k, v) for k, v in table.items() if "_kernel" in k), key=lambda kv: kv[1]["ms"])
-        sec = r["ms"] / 1e3
-        peak_mfma = PEAK_F16_MFMA_TFLOPS if args.dtype == "f16" else PEAK_F32_MFMA_TFLOPS
-        t_mfma, t_hbm = r["flops"] / (peak_mfma * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)
-        if t_mfma >= t_hbm:
-            ach = r["flops"] / sec / 1e12
-            roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak_mfma, "unit": "TFLOP/s",
-                        "frac": round(ach / peak_mfma, 4), "traffic": None}
-        else:
-            ach = r["bytes"] / sec / 1e9
-            roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None}
+        # the dominant kernel = the symbol with the largest share of GPU time among ALL launches of the step, whichever call made
+        # them (the library times each launch itself, so a call that launches two kernels contributes two rows)
+        sym, r = max(table.items(), key=lambda kv: kv[1]["ms"])
+        bound, ach, unit, peak, frac = against_roofs(r)
+        roofline = {"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": frac, "traffic": None}
         roofline["algorithmic_bytes_per_launch"] = round(r["bytes"] / r["launches"])
+        roofline["algorithmic_flop_per_launch"] = round(r["flops"] / r["launches"])
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic(sym, args)
         # per-launch durations are taken with the step on ONE stream (EnhancedCycleGAN drops its side streams while
         # ops.KernelTimer is enabled): on two streams launches overlap and a launch's event-to-event time includes its neighbour
-        roofline["measured"] = "instrumented step on one stream (MSTG_STREAMS=0 equivalent)"
+        roofline["measured"] = "HIP events around every kernel launch (mstg_prof_*), instrumented step on one stream"
         roofline.update({"kernel": sym, "launches_per_step": r["launches"], "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2),
-                         "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2)})
-        # the largest timed CALL regardless of how many kernels it launches (the InstanceNorm backward = norm_partial_kernel<true> +
-        # norm_apply_kernel<true> is the largest share of the headline step): same arithmetic, so the reader sees both
-        lsym, lr = max(table.items(), key=lambda kv: kv[1]["ms"])
-        lt_mfma, lt_hbm = lr["flops"] / (peak_mfma * 1e12), lr["bytes"] / (PEAK_HBM_GBS * 1e9)
-        lsec = lr["ms"] / 1e3
-        roofline["largest_call"] = {"name": lsym, "launches_per_step": lr["launches"], "ms_per_step": round(lr["ms"], 3),
-                                    "share_of_gpu_time": round(lr["ms"] / total_ms, 3), "bound": "mfma" if lt_mfma >= lt_hbm else "hbm",
-                                    "achieved": round(lr["flops"] / lsec / 1e12, 3) if lt_mfma >= lt_hbm else round(lr["bytes"] / lsec / 1e9, 1),
-                                    "unit": "TFLOP/s" if lt_mfma >= lt_hbm else "GB/s",
-                                    "frac": round((lr["flops"] / lsec / 1e12) / peak_mfma if lt_mfma >= lt_hbm else (lr["bytes"] / lsec / 1e9) / PEAK_HBM_GBS, 4)}
+                         "share_of_gpu_time": round(r["ms"] / total_ms, 3), "instrumented_step_gpu_ms": round(total_ms, 2),
+                         "launches_in_step": sum(v["launches"] for v in table.values())})
+        # the five largest symbols, same arithmetic (so the reader sees what stands behind the dominant one)
+        roofline["top"] = []
+        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"])[:5]:
+            b_, a_, u_, _, f_ = against_roofs(v)
+            roofline["top"].append({"kernel": k, "launches": v["launches"], "ms": round(v["ms"], 3), "bound": b_, "achieved": a_, "unit": u_, "frac": f_})
+        # the largest OP (C-ABI call incl. its helper launches): algorithmic work of the op / time of all its kernels
+        lsym, lr = max(calls.items(), key=lambda kv: kv[1]["ms"])
+        b_, a_, u_, _, f_ = against_roofs(lr)
+        roofline["largest_call"] = {"name": lsym, "kernels": sorted(lr.get("kernels", ())), "calls_per_step": lr["launches"],
+                                    "ms_per_step": round(lr["ms"], 3), "share_of_gpu_time": round(lr["ms"] / total_ms, 3),
+                                    "bound": b_, "achieved": a_, "unit": u_, "frac": f_}
         # whole-step view against both roofs (algorithmic work of every timed launch / wall time of the timed region)
         tot_fl, tot_by = sum(v["flops"] for v in table.values()), sum(v["bytes"] for v in table.values())
         roofline["step"] = {"algorithmic_tflop": round(tot_fl / 1e12, 4), "algorithmic_gb": round(tot_by / 1e9, 3),

@@ -43,6 +43,14 @@ const char* mstg_last_error(void); /* text of the last failing HIP call on this 
 /* The MSTG_* environment switches are read when the library is loaded; call this after changing one. */
 void mstg_env_refresh(void);
 
+/* Per-launch profiler (measurement only; bench.py's `roofline` object).  While enabled, every kernel the library launches is
+ * bracketed by two HIP events on the stream it is launched on.  mstg_prof_enable(1) clears earlier records; mstg_prof_get
+ * waits for record i and returns its kernel symbol (as rocprofv3 --kernel-trace prints it, without return type, namespace and
+ * parameter list) and its duration in milliseconds.  Off by default: no events are created on the product path. */
+int mstg_prof_enable(int on);
+int mstg_prof_count(void);
+int mstg_prof_get(int i, char* name, size_t name_cap, float* ms);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolutions.  One descriptor describes the MODULE (nn.Conv2d or nn.ConvTranspose2d); the three
  * entry points are its forward, its input gradient and its weight/bias gradient.

@@ -34,6 +34,9 @@ SIGNATURES = {
     "mstg_arch": (C.c_char_p, []),
     "mstg_last_error": (C.c_char_p, []),
     "mstg_env_refresh": (None, []),
+    "mstg_prof_enable": (_i, [_i]),
+    "mstg_prof_count": (_i, []),
+    "mstg_prof_get": (_i, [_i, C.c_char_p, _sz, C.POINTER(C.c_float)]),
     "mstg_conv2d_kernel_name": (C.c_char_p, [_dp, _i]),
     "mstg_conv2d_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),

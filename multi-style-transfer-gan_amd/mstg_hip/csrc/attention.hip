@@ -726,10 +726,10 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
     const int nb = fused_blocks(N, H, W);
     if (!bwd) {
         if (in_stats)
-            hipLaunchKernelGGL((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+            MSTG_LAUNCH((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
                                out, N, H, W, in_stats);
         else
-            hipLaunchKernelGGL((attn_fused_fwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+            MSTG_LAUNCH((attn_fused_fwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
                                out, N, H, W, in_stats);
         MSTG_CHECK_LAUNCH("attn_fused_fwd_kernel");
         return MSTG_OK;
@@ -737,17 +737,17 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
     if (in_stats) {
         float* nsum = partial + (size_t)nb * F::SLAB;
         const int kblk = norm_run_len(H, W), R = (H / 4) * (W / 4) / kblk;
-        hipLaunchKernelGGL((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+        MSTG_LAUNCH((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
                            out, partial, N, H, W, in_stats, nsum, kblk);
         MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel<norm>");
-        hipLaunchKernelGGL(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
+        MSTG_LAUNCH(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
         MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
     } else {
-        hipLaunchKernelGGL((attn_fused_bwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+        MSTG_LAUNCH((attn_fused_bwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
                            out, partial, N, H, W, in_stats, (float*)nullptr, 1);
         MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
     }
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB);
+    MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB);
     MSTG_CHECK_LAUNCH("slab_reduce_kernel");
     return MSTG_OK;
 }
@@ -1206,8 +1206,8 @@ static int launch_attn_blk4(bool bwd, const float* qkv, const float* d_o, float*
         if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_blk4)");
         set = true;
     }
-    if (bwd) hipLaunchKernelGGL((attn_core_bwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, d_o, out, N, H, W, C);
-    else hipLaunchKernelGGL((attn_core_fwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, out, N, H, W, C);
+    if (bwd) MSTG_LAUNCH((attn_core_bwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, d_o, out, N, H, W, C);
+    else MSTG_LAUNCH((attn_core_fwd_blk4_kernel<CP>), dim3(grid), dim3(256), lds, st, qkv, out, N, H, W, C);
     MSTG_CHECK_LAUNCH("attn_core_blk4_kernel");
     return MSTG_OK;
 }
@@ -1231,8 +1231,8 @@ static int launch_attn_blk(bool bwd, const float* qkv, const float* d_o, float* 
         if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_blk)");
         set = true;
     }
-    if (bwd) hipLaunchKernelGGL((attn_core_bwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
-    else hipLaunchKernelGGL((attn_core_fwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
+    if (bwd) MSTG_LAUNCH((attn_core_bwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
+    else MSTG_LAUNCH((attn_core_fwd_blk_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
     MSTG_CHECK_LAUNCH("attn_core_blk_kernel");
     return MSTG_OK;
 }
@@ -1271,9 +1271,9 @@ static int launch_attn(bool bwd, const float* qkv, const float* d_o, float* out,
             if (e != hipSuccess) return fail_launch(e, "hipFuncSetAttribute(attn_bwd)");
             set = true;
         }
-        hipLaunchKernelGGL((attn_core_bwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
+        MSTG_LAUNCH((attn_core_bwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, d_o, out, N, H, W, C);
     } else {
-        hipLaunchKernelGGL((attn_core_fwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
+        MSTG_LAUNCH((attn_core_fwd_kernel<CP>), dim3(grid), dim3(64), lds, st, qkv, out, N, H, W, C);
     }
     MSTG_CHECK_LAUNCH("attn_core_kernel");
     return MSTG_OK;

@@ -28,6 +28,21 @@ inline int fail_arg(int code, const char* what) {
         if (e__ != hipSuccess) return mstg::fail_launch(e__, what); \
     } while (0)
 
+// ---- per-launch profiler (mstg_prof_*, include/mstg_hip.h) -----------------------------------------------------------
+// Every kernel of the library is launched through MSTG_LAUNCH.  With profiling on (bench.py's roofline leg) the launch is
+// bracketed by two HIP events on ITS stream and recorded under the symbol hipKernelNameRefByPtr reports (demangled: the name
+// rocprofv3 prints), so per-kernel durations exist even where one C-ABI call launches several kernels.
+extern bool g_prof_on;
+void prof_begin(const void* host_fn, hipStream_t st);
+void prof_end(hipStream_t st);
+#define MSTG_LAUNCH(kern, grid, block, lds, st, ...)                               \
+    do {                                                                           \
+        const bool prof__ = mstg::g_prof_on;                                       \
+        if (prof__) mstg::prof_begin((const void*)(kern), (hipStream_t)(st));      \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);               \
+        if (prof__) mstg::prof_end((hipStream_t)(st));                             \
+    } while (0)
+
 // ---- runtime switches ------------------------------------------------------------------------------------------------
 // The MSTG_* environment switches are read ONCE, when the library is loaded, and again on
 // mstg_env_refresh(): a train step makes ~1400 launches and each planner used to call getenv() several times per launch.

@@ -979,7 +979,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
 static int launch_pack(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
     const int npack = p.ncls * p.nchunks * a.ntaps * p.CoP * p.CK;
     const int nb = cdiv(npack, 256) > 256 ? 256 : cdiv(npack, 256);
-    hipLaunchKernelGGL(pack_filter_kernel, dim3(nb), dim3(256), 0, st, a, wp, p.CK, p.CoP, p.nchunks, p.ncls);
+    MSTG_LAUNCH(pack_filter_kernel, dim3(nb), dim3(256), 0, st, a, wp, p.CK, p.CoP, p.nchunks, p.ncls);
     MSTG_CHECK_LAUNCH("pack_filter_kernel");
     return MSTG_OK;
 }
@@ -994,7 +994,7 @@ static int launch_light_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
         attr_set = true;
     }
     dim3 grid(a.N * a.tiles_x * a.tiles_y, p.CoP / p.BN, p.ncls);
-    hipLaunchKernelGGL((igemm_light_kernel<V, NFW, PF>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_LAUNCH((igemm_light_kernel<V, NFW, PF>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
     MSTG_CHECK_LAUNCH("igemm_light_kernel");
     return MSTG_OK;
 }
@@ -1009,7 +1009,7 @@ static int launch_stream_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStrea
         attr_set = true;
     }
     dim3 grid(p.gx, p.CoP / p.BN, p.ncls);
-    hipLaunchKernelGGL((igemm_stream_kernel<V, NFW, PF, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_LAUNCH((igemm_stream_kernel<V, NFW, PF, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
     MSTG_CHECK_LAUNCH("igemm_stream_kernel");
     return MSTG_OK;
 }
@@ -1032,7 +1032,7 @@ static int launch_heavy_t(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream
     gx = gx < 8 ? 8 : (gx & ~7);
     if (gx > ntiles) gx = ntiles;
     dim3 grid(gx, ny, nz);
-    hipLaunchKernelGGL((igemm_heavy_kernel<V, NFW, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
+    MSTG_LAUNCH((igemm_heavy_kernel<V, NFW, SRC>), grid, dim3(256), p.lds, st, a, (const float*)wp, p.CoP);
     MSTG_CHECK_LAUNCH("igemm_heavy_kernel");
     return MSTG_OK;
 }

@@ -656,7 +656,7 @@ static int p32d_launch_t(const P32Args& a, const P32dPlan& p, int act, size_t ld
     }
     long g_ = 256L * occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p, act);
+    MSTG_LAUNCH(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p, act);
     MSTG_CHECK_LAUNCH("conv_p32d_kernel");
     return MSTG_OK;
 }
@@ -679,7 +679,7 @@ static int launch_p32d(const IGemmArgs& g, void* workspace, size_t workspace_byt
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: tensor too large for the 32-bit tile arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    hipLaunchKernelGGL(p32d_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_LAUNCH(p32d_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32d_pack_kernel");
     size_t patch = (size_t)p.PH * p.PW * p.pixstride;
     if (patch < (size_t)4 * 256 * (TH / 4) * sizeof(float)) patch = (size_t)4 * 256 * (TH / 4) * sizeof(float);  // the exchange tiles live there too
@@ -739,7 +739,7 @@ static bool co1_eligible(const IGemmArgs& a) {
 
 static int launch_co1(const IGemmArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(a.KH * a.KW * a.Cr + 256) * sizeof(float);
-    hipLaunchKernelGGL(conv_co1_kernel, dim3(a.Ho, a.N), dim3(256), lds, st, a.x, a.w, a.bias, a.y, a.H, a.W, a.Cr, a.Ho, a.Wo, a.KH, a.KW,
+    MSTG_LAUNCH(conv_co1_kernel, dim3(a.Ho, a.N), dim3(256), lds, st, a.x, a.w, a.bias, a.y, a.H, a.W, a.Cr, a.Ho, a.Wo, a.KH, a.KW,
                        a.pad, a.w_sr);
     MSTG_CHECK_LAUNCH("conv_co1_kernel");
     return MSTG_OK;
@@ -785,7 +785,7 @@ static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_byt
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: tensor too large for the 32-bit tile arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    hipLaunchKernelGGL(p32i_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_LAUNCH(p32i_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32i_pack_kernel");
     const size_t lds = (size_t)P32I_MAX_STEPS * 16 + (size_t)p.nsteps * 1024 + (size_t)p.PH * p.PW * 16;
     static int occ = 0;
@@ -800,7 +800,7 @@ static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_byt
     { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < occ_) occ_ = atoi(e); }
     long g_ = 256L * occ_;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL(conv_p32i_kernel, dim3((unsigned)g_), dim3(256), lds, st, a, p);
+    MSTG_LAUNCH(conv_p32i_kernel, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32i_kernel");
     return MSTG_OK;
 }
@@ -929,11 +929,11 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
     { const char* e = env_get(ENV_P32_OCC); if (e && atoi(e) >= 1 && atoi(e) < c_occ) c_occ = atoi(e); }  // experiments: leave room for the other stream
     long g_ = 256L * c_occ;
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
-    hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
+    MSTG_LAUNCH(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32_kernel");
     if (out_stats) {
         const int ntile = a.tiles_x * a.tiles_y;
-        hipLaunchKernelGGL(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
+        MSTG_LAUNCH(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
                            (float)((size_t)a.Ho * a.Wo), ntile, (int)((tiles + g_ - 1) / g_));
         MSTG_CHECK_LAUNCH("p32_norm_finalize_kernel");
     }
@@ -989,7 +989,7 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: tensor too large for the 32-bit tile / offset arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    hipLaunchKernelGGL(p32_pack_kernel, dim3(32), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_LAUNCH(p32_pack_kernel, dim3(32), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32_pack_kernel");
     size_t lds = P32_TABLE_BYTES + (size_t)p.PH * p.PW * p.pixstride + (p.wlds ? (size_t)p.nsteps * p.NF * 1024 : 0);
     lds = (lds + 15) & ~(size_t)15;

@@ -902,7 +902,7 @@ template <int MF, int NW>
 static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st, const float* in_stats = nullptr) {
     const int NF = cdiv(a.Ch, 16), P1 = wgrad_1x1_tile(a.Cg, a.Ch);
     const size_t lds = (size_t)P1 * ((16 * MF + 4) + (16 * NF + 4)) * sizeof(float);
-    hipLaunchKernelGGL((wgrad_1x1_kernel<MF, NW>), dim3(S), dim3(256), lds, st, a.g, a.h, a.partial, P, a.Cg, a.g_ctot, a.g_coff, a.Ch,
+    MSTG_LAUNCH((wgrad_1x1_kernel<MF, NW>), dim3(S), dim3(256), lds, st, a.g, a.h, a.partial, P, a.Cg, a.g_ctot, a.g_coff, a.Ch,
                        a.h_ctot, a.h_coff, a.with_bias, P1, in_stats, a.hH * a.hW);
     MSTG_CHECK_LAUNCH("wgrad_1x1_kernel");
     return MSTG_OK;
@@ -1027,7 +1027,7 @@ static int launch_wgrad_t(WGradArgs& a, const WGradPlan& p, hipStream_t st) {
     }
     const int ny = a.n_gchunks * (a.mode == MODE_DPACK ? 1 : cdiv(a.Ch, 16 * NFH));
     dim3 grid(p.S, ny, p.nz);
-    hipLaunchKernelGGL((wgrad_kernel<TG, NFH>), grid, dim3(256), p.lds, st, a);
+    MSTG_LAUNCH((wgrad_kernel<TG, NFH>), grid, dim3(256), p.lds, st, a);
     MSTG_CHECK_LAUNCH("wgrad_kernel");
     return MSTG_OK;
 }
@@ -1080,7 +1080,7 @@ static int launch_ts_t(WGradArgs& a, const TsPlan& p, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(p.S, a.n_gchunks * p.ngroups, 1);
-    hipLaunchKernelGGL((wgrad_ts_kernel<UW>), grid, dim3(256), p.lds, st, a, p.TH, p.NFHT);
+    MSTG_LAUNCH((wgrad_ts_kernel<UW>), grid, dim3(256), p.lds, st, a, p.TH, p.NFHT);
     MSTG_CHECK_LAUNCH("wgrad_ts_kernel");
     return MSTG_OK;
 }
@@ -1124,7 +1124,7 @@ static int launch_wp(WGradArgs& a, WpPlan& p, hipStream_t st) {
     if (S > p.S) S = p.S;
     if (S < 1) S = 1;
     p.S = S;
-    hipLaunchKernelGGL(wgrad_p32_kernel, dim3(S, p.ny, 1), dim3(256), p.lds, st, a);
+    MSTG_LAUNCH(wgrad_p32_kernel, dim3(S, p.ny, 1), dim3(256), p.lds, st, a);
     MSTG_CHECK_LAUNCH("wgrad_p32_kernel");
     return MSTG_OK;
 }
@@ -1151,8 +1151,8 @@ static int w7_splits(const WGradArgs& a) {
 }
 static int launch_w7(WGradArgs& a, int S, hipStream_t st) {
     const size_t lds = w7_lds(a);
-    if (a.mode == MODE_PACKX) hipLaunchKernelGGL((wgrad7_kernel<MODE_PACKX>), dim3(S), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((wgrad7_kernel<MODE_DPACK>), dim3(S), dim3(256), lds, st, a);
+    if (a.mode == MODE_PACKX) MSTG_LAUNCH((wgrad7_kernel<MODE_PACKX>), dim3(S), dim3(256), lds, st, a);
+    else MSTG_LAUNCH((wgrad7_kernel<MODE_DPACK>), dim3(S), dim3(256), lds, st, a);
     MSTG_CHECK_LAUNCH("wgrad7_kernel");
     return MSTG_OK;
 }
@@ -1299,7 +1299,7 @@ static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const floa
                 if (rc) return rc;
                 // the partial slabs are reused by the next block: stream order keeps this reduce ahead of the next launch
                 const int pstride = b.Cg * b.Ch + (b.with_bias ? b.Ch : 0);
-                hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial,
+                MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial,
                                    dw + (size_t)(ig * c.wg) * s_g + (size_t)(ih * c.wh) * s_h, b.with_bias ? dbias + ih * c.wh : nullptr, Sb, 1,
                                    b.Cg, b.Ch, s_g, s_h, pstride, d->accumulate);
                 MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -1344,7 +1344,7 @@ static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const floa
     const int s_g = T;
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
     const int pstride = total + (a.with_bias ? a.Ch : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
+    MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
                        pstride, d->accumulate);
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;

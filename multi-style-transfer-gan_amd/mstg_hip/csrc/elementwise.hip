@@ -277,7 +277,7 @@ using namespace mstg;
 extern "C" int mstg_act_fwd(const float* x, float* y, size_t n, int act, void* stream) {
     if (!x || !y) return fail_arg(MSTG_E_BADARG, "act_fwd: null pointer");
     if (n == 0) return MSTG_OK;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, n, act);
+    MSTG_LAUNCH(act_fwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, y, n, act);
     MSTG_CHECK_LAUNCH("act_fwd_kernel");
     return MSTG_OK;
 }
@@ -285,7 +285,7 @@ extern "C" int mstg_act_fwd(const float* x, float* y, size_t n, int act, void* s
 extern "C" int mstg_act_bwd(const float* x_or_y, const float* dy, float* dx, size_t n, int act, void* stream) {
     if (!x_or_y || !dy || !dx) return fail_arg(MSTG_E_BADARG, "act_bwd: null pointer");
     if (n == 0) return MSTG_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x_or_y, dy, dx, n, act);
+    MSTG_LAUNCH(act_bwd_kernel, dim3(ew_grid(n >> 2)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x_or_y, dy, dx, n, act);
     MSTG_CHECK_LAUNCH("act_bwd_kernel");
     return MSTG_OK;
 }
@@ -303,9 +303,9 @@ extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, 
     if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "loss_fwd: workspace too small");
     const int nb = ew_grid(n);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, bconst, n, kind, (float*)workspace);
+    MSTG_LAUNCH(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, bconst, n, kind, (float*)workspace);
     MSTG_CHECK_LAUNCH("loss_partial_kernel");
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
+    MSTG_LAUNCH(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
     MSTG_CHECK_LAUNCH("loss_final_kernel");
     return MSTG_OK;
 }
@@ -314,7 +314,7 @@ extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, 
 extern "C" int mstg_add(const float* a, const float* b, float* y, size_t n, void* stream) {
     if (!a || !b || !y) return fail_arg(MSTG_E_BADARG, "add: null pointer");
     if (n == 0) return MSTG_OK;
-    hipLaunchKernelGGL(add_kernel, dim3(ew_grid((n >> 2) + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, y, n);
+    MSTG_LAUNCH(add_kernel, dim3(ew_grid((n >> 2) + 1)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, y, n);
     MSTG_CHECK_LAUNCH("add_kernel");
     return MSTG_OK;
 }
@@ -326,9 +326,9 @@ extern "C" int mstg_masked_l1_mean_fwd(const float* a, const float* b, const flo
     if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "masked_l1_fwd: workspace too small");
     const int nb = ew_grid(n);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(masked_l1_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, m, n, (float*)workspace);
+    MSTG_LAUNCH(masked_l1_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, a, b, m, n, (float*)workspace);
     MSTG_CHECK_LAUNCH("masked_l1_partial_kernel");
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
+    MSTG_LAUNCH(loss_final_kernel, dim3(1), dim3(EW_BLOCK), 0, st, (const float*)workspace, nb, 1.f / (float)n, out);
     MSTG_CHECK_LAUNCH("loss_final_kernel");
     return MSTG_OK;
 }
@@ -337,7 +337,7 @@ extern "C" int mstg_masked_l1_mean_bwd(const float* a, const float* b, const flo
                                        void* stream) {
     if (!a || !b || !m || !da) return fail_arg(MSTG_E_BADARG, "masked_l1_bwd: null pointer");
     if (n == 0) return fail_arg(MSTG_E_BADARG, "masked_l1_bwd: empty tensor");
-    hipLaunchKernelGGL(masked_l1_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, m, n, gscale, da);
+    MSTG_LAUNCH(masked_l1_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, m, n, gscale, da);
     MSTG_CHECK_LAUNCH("masked_l1_bwd_kernel");
     return MSTG_OK;
 }
@@ -350,9 +350,9 @@ extern "C" int mstg_clip_grad_norm(float* g, size_t n, float max_norm, float* no
     if (workspace_bytes < mstg_loss_workspace_bytes(n)) return fail_arg(MSTG_E_WORKSPACE, "clip_grad_norm: workspace too small");
     const int nb = ew_grid(n);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, (const float*)g, (const float*)nullptr, 0.f, n, 1, (float*)workspace);
+    MSTG_LAUNCH(loss_partial_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, (const float*)g, (const float*)nullptr, 0.f, n, 1, (float*)workspace);
     MSTG_CHECK_LAUNCH("loss_partial_kernel");
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, g, n, (const float*)workspace, nb, max_norm, norm_out);
+    MSTG_LAUNCH(clip_scale_kernel, dim3(nb), dim3(EW_BLOCK), 0, st, g, n, (const float*)workspace, nb, max_norm, norm_out);
     MSTG_CHECK_LAUNCH("clip_scale_kernel");
     return MSTG_OK;
 }
@@ -362,7 +362,7 @@ extern "C" int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, 
     if (!a || !da) return fail_arg(MSTG_E_BADARG, "loss_bwd: null pointer");
     if (n == 0) return fail_arg(MSTG_E_BADARG, "loss_bwd: empty tensor");
     if (kind != 0 && kind != 1) return fail_arg(MSTG_E_BADARG, "loss_bwd: kind must be 0 (L1) or 1 (MSE)");
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, bconst, n, kind, gscale, scale, da, db);
+    MSTG_LAUNCH(loss_bwd_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, a, b, bconst, n, kind, gscale, scale, da, db);
     MSTG_CHECK_LAUNCH("loss_bwd_kernel");
     return MSTG_OK;
 }
@@ -381,12 +381,12 @@ extern "C" int mstg_channel_sum(const float* x, size_t P, int ctot, int coff, in
     const int threads = C <= 256 ? 256 : 1024;
     hipStream_t st = (hipStream_t)stream;
     if (((ctot | coff | C) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-        hipLaunchKernelGGL(channel_sum_partial_v4_kernel, dim3(nb), dim3(threads), (size_t)(threads / (C / 4)) * C * sizeof(float), st, x, P, ctot,
+        MSTG_LAUNCH(channel_sum_partial_v4_kernel, dim3(nb), dim3(threads), (size_t)(threads / (C / 4)) * C * sizeof(float), st, x, P, ctot,
                            coff, C, (float*)workspace);
     else
-        hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nb), dim3(threads), threads * sizeof(float), st, x, P, ctot, coff, C, (float*)workspace);
+        MSTG_LAUNCH(channel_sum_partial_kernel, dim3(nb), dim3(threads), threads * sizeof(float), st, x, P, ctot, coff, C, (float*)workspace);
     MSTG_CHECK_LAUNCH("channel_sum_partial_kernel");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    MSTG_LAUNCH(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
     MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
     return MSTG_OK;
 }
@@ -403,9 +403,9 @@ extern "C" int mstg_plane_sum(const float* x, int N, int C, size_t HW, float sca
     if (workspace_bytes < mstg_plane_sum_workspace_bytes(N, C, HW)) return fail_arg(MSTG_E_WORKSPACE, "plane_sum: workspace too small");
     const int nb = channel_sum_blocks((size_t)N * HW);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(plane_sum_partial_kernel, dim3(nb, C), dim3(256), 0, st, x, N, C, HW, (float*)workspace);
+    MSTG_LAUNCH(plane_sum_partial_kernel, dim3(nb, C), dim3(256), 0, st, x, N, C, HW, (float*)workspace);
     MSTG_CHECK_LAUNCH("plane_sum_partial_kernel");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
+    MSTG_LAUNCH(channel_sum_final_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, nb, C, scale, out);
     MSTG_CHECK_LAUNCH("channel_sum_final_kernel");
     return MSTG_OK;
 }
@@ -414,7 +414,7 @@ extern "C" int mstg_segment_mean_fwd(const float* x, int S, size_t P, int C, flo
     if (!x || !out) return fail_arg(MSTG_E_BADARG, "segment_mean: null pointer");
     if (S <= 0 || P == 0 || C <= 0 || C > 1024) return fail_arg(MSTG_E_BADARG, "segment_mean: bad shape");
     const int threads = C <= 256 ? 256 : 1024;
-    hipLaunchKernelGGL(segment_sum_kernel, dim3(S), dim3(threads), threads * sizeof(float), (hipStream_t)stream, x, P, C, 1.f / (float)P, out);
+    MSTG_LAUNCH(segment_sum_kernel, dim3(S), dim3(threads), threads * sizeof(float), (hipStream_t)stream, x, P, C, 1.f / (float)P, out);
     MSTG_CHECK_LAUNCH("segment_sum_kernel");
     return MSTG_OK;
 }
@@ -423,7 +423,7 @@ extern "C" int mstg_segment_mean_bwd(const float* dy, int S, size_t P, int C, fl
     if (!dy || !dx) return fail_arg(MSTG_E_BADARG, "segment_mean_bwd: null pointer");
     if (S <= 0 || P == 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "segment_mean_bwd: bad shape");
     const size_t total = (size_t)S * P * C;
-    hipLaunchKernelGGL(segment_broadcast_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dy, P, C, 1.f / (float)P, dx, total);
+    MSTG_LAUNCH(segment_broadcast_kernel, dim3(ew_grid(total)), dim3(EW_BLOCK), 0, (hipStream_t)stream, dy, P, C, 1.f / (float)P, dx, total);
     MSTG_CHECK_LAUNCH("segment_broadcast_kernel");
     return MSTG_OK;
 }
@@ -434,7 +434,7 @@ extern "C" int mstg_adam_step_flat(float* p, const float* g, float* m, float* v,
     if (step < 1) return fail_arg(MSTG_E_BADARG, "adam: step counts from 1");
     if (n == 0) return MSTG_OK;
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
+    MSTG_LAUNCH(adam_kernel, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1,
                        (float)sqrt(bc2), mask);
     MSTG_CHECK_LAUNCH("adam_kernel");
     return MSTG_OK;

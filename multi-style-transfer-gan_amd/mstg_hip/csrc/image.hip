@@ -182,7 +182,7 @@ extern "C" int mstg_resample_h_u8(const unsigned char* src, unsigned char* dst, 
     if (!src || !dst || !kk || !bounds || src_w <= 0 || rows <= 0 || out_w <= 0 || ksize <= 0 || y0 < 0)
         return fail_arg(MSTG_E_BADARG, "resample_h_u8: bad argument");
     if (rows > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "resample_h_u8: more than 65535 rows");
-    hipLaunchKernelGGL(resample_h_u8_kernel, dim3(cdiv(out_w, 128), rows), dim3(128), 0, (hipStream_t)stream, src, dst, src_w, y0, rows,
+    MSTG_LAUNCH(resample_h_u8_kernel, dim3(cdiv(out_w, 128), rows), dim3(128), 0, (hipStream_t)stream, src, dst, src_w, y0, rows,
                        out_w, ksize, kk, bounds);
     MSTG_CHECK_LAUNCH("resample_h_u8_kernel");
     return MSTG_OK;
@@ -192,7 +192,7 @@ extern "C" int mstg_resample_v_u8(const unsigned char* src, unsigned char* dst, 
                                   const int* bounds, void* stream) {
     if (!src || !dst || !kk || !bounds || w <= 0 || out_h <= 0 || ksize <= 0) return fail_arg(MSTG_E_BADARG, "resample_v_u8: bad argument");
     if (out_h > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "resample_v_u8: more than 65535 rows");
-    hipLaunchKernelGGL(resample_v_u8_kernel, dim3(cdiv(w, 128), out_h), dim3(128), 0, (hipStream_t)stream, src, dst, w, out_h, ksize, kk,
+    MSTG_LAUNCH(resample_v_u8_kernel, dim3(cdiv(w, 128), out_h), dim3(128), 0, (hipStream_t)stream, src, dst, w, out_h, ksize, kk,
                        bounds);
     MSTG_CHECK_LAUNCH("resample_v_u8_kernel");
     return MSTG_OK;
@@ -203,7 +203,7 @@ extern "C" int mstg_paste_u8(const unsigned char* src, int sh, int sw, int sy0, 
     if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || ch < 0 || cw < 0) return fail_arg(MSTG_E_BADARG, "paste_u8: bad argument");
     if (sy0 < 0 || sx0 < 0 || sy0 + ch > sh || sx0 + cw > sw) return fail_arg(MSTG_E_BADARG, "paste_u8: source window outside the image");
     if (dh > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "paste_u8: more than 65535 rows");
-    hipLaunchKernelGGL(paste_u8_kernel, dim3(cdiv(dw, 128), dh), dim3(128), 0, (hipStream_t)stream, src, sh, sw, sy0, sx0, ch, cw, dst, dh,
+    MSTG_LAUNCH(paste_u8_kernel, dim3(cdiv(dw, 128), dh), dim3(128), 0, (hipStream_t)stream, src, sh, sw, sy0, sx0, ch, cw, dst, dh,
                        dw, dy0, dx0, fill < 0 ? 0 : fill, fill >= 0 ? 1 : 0);
     MSTG_CHECK_LAUNCH("paste_u8_kernel");
     return MSTG_OK;
@@ -214,7 +214,7 @@ extern "C" int mstg_u8_to_tensor(const unsigned char* src, int sh, int sw, int y
     if (!src || !out || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "u8_to_tensor: bad argument");
     if (y0 < 0 || x0 < 0 || y0 + H > sh || x0 + W > sw) return fail_arg(MSTG_E_BADARG, "u8_to_tensor: window outside the image");
     if (H > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "u8_to_tensor: more than 65535 rows");
-    hipLaunchKernelGGL(u8_to_tensor_kernel, dim3(cdiv(W, 128), H), dim3(128), 0, (hipStream_t)stream, src, sw, y0, x0, H, W, out, image_out,
+    MSTG_LAUNCH(u8_to_tensor_kernel, dim3(cdiv(W, 128), H), dim3(128), 0, (hipStream_t)stream, src, sw, y0, x0, H, W, out, image_out,
                        mask_out, grid, use_mask);
     MSTG_CHECK_LAUNCH("u8_to_tensor_kernel");
     return MSTG_OK;
@@ -223,7 +223,7 @@ extern "C" int mstg_u8_to_tensor(const unsigned char* src, int sh, int sw, int y
 extern "C" int mstg_tensor_to_u8(const float* y, int H, int W, unsigned char* dst, void* stream) {
     if (!y || !dst || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "tensor_to_u8: bad argument");
     if (H > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "tensor_to_u8: more than 65535 rows");
-    hipLaunchKernelGGL(tensor_to_u8_kernel, dim3(cdiv(W, 128), H), dim3(128), 0, (hipStream_t)stream, y, H, W, dst);
+    MSTG_LAUNCH(tensor_to_u8_kernel, dim3(cdiv(W, 128), H), dim3(128), 0, (hipStream_t)stream, y, H, W, dst);
     MSTG_CHECK_LAUNCH("tensor_to_u8_kernel");
     return MSTG_OK;
 }

@@ -989,7 +989,7 @@ static int launch_conv(const F16ConvArgs& a, const F16Plan& p, int src, int dst,
         if (a.partial && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * NF * sizeof(float), st) != hipSuccess)   \
             return fail_arg(MSTG_E_LAUNCH, "f16 conv: clearing the statistics partials failed");                           \
         *grid_out = (int)g_;                                                                                              \
-        hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);                                           \
+        MSTG_LAUNCH(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);                                           \
     } while (0)
     if (src == 0 && dst == 0) MSTG_F16_LAUNCH(0, 0);
     else if (src == 1 && dst == 0) MSTG_F16_LAUNCH(1, 0);
@@ -1036,7 +1036,7 @@ extern "C" int mstg_f16_conv_pack(const mstg_f16_conv_desc* d, const float* w0, 
     s.Cin = d->Cin; s.Cout = d->Cout; s.KH = s.KW = d->K; s.c4 = d->kind == 2 ? d->Cin / 4 : 0;
     float* bias = (float*)blob;
     h16* wpk = (h16*)((char*)blob + 256);
-    hipLaunchKernelGGL(f16_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *pt, s, p.nwfrag, p.NF, wpk, bias);
+    MSTG_LAUNCH(f16_pack_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *pt, s, p.nwfrag, p.NF, wpk, bias);
     delete pt;
     MSTG_CHECK_LAUNCH("f16_pack_kernel");
     return MSTG_OK;
@@ -1111,7 +1111,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
                 if (a.partial && hipMemsetAsync(a.partial, 0, (size_t)a.N * g_ * 2 * 16 * p.NF * sizeof(float), st) != hipSuccess)
                     return fail_arg(MSTG_E_LAUNCH, "f16 conv: clearing the statistics partials failed");
                 launched = (int)g_;
-                hipLaunchKernelGGL(kern, dim3((unsigned)g_), dim3(256), 0, st, a, p);
+                MSTG_LAUNCH(kern, dim3((unsigned)g_), dim3(256), 0, st, a, p);
                 MSTG_CHECK_LAUNCH("conv1x1_f16_kernel");
                 return MSTG_OK;
             };
@@ -1125,7 +1125,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
             if (rc != MSTG_E_UNSUPPORTED) {
                 if (rc) return rc;
                 if (out_stats) {
-                    hipLaunchKernelGGL(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, launched,
+                    MSTG_LAUNCH(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, launched,
                                        16 * p.NF, d->Cout, (float)((size_t)d->Ho * d->Wo));
                     MSTG_CHECK_LAUNCH("f16_norm_finalize_kernel");
                 }
@@ -1156,7 +1156,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     if (out_stats) {
         const float count = (float)((size_t)d->Ho * d->Wo);
         // ConvTranspose: each compute-grid tile wrote 4 classes; the per-tile sums already cover all of them
-        hipLaunchKernelGGL(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats,
+        MSTG_LAUNCH(f16_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats,
                            launched, 16 * p.NF, d->Cout, count);
         MSTG_CHECK_LAUNCH("f16_norm_finalize_kernel");
     }
@@ -1172,7 +1172,7 @@ extern "C" int mstg_f16_norm_residual(const void* x, const void* residual, const
     int bpi = (int)((chunks + 256 * 8 - 1) / (256 * 8));  // ~8 chunks per thread
     if (bpi > 4096) bpi = 4096;
     if (bpi < 1) bpi = 1;
-    hipLaunchKernelGGL(f16_norm_residual_kernel, dim3((unsigned)N * bpi), dim3(256), 0, (hipStream_t)stream, (const h16*)x,
+    MSTG_LAUNCH(f16_norm_residual_kernel, dim3((unsigned)N * bpi), dim3(256), 0, (hipStream_t)stream, (const h16*)x,
                        (const h16*)residual, stats, (h16*)y, (size_t)HW, C, bpi);
     MSTG_CHECK_LAUNCH("f16_norm_residual_kernel");
     return MSTG_OK;
@@ -1399,7 +1399,7 @@ extern "C" int mstg_f16_attn_pack(const float* wqkv, const float* bqkv, const fl
     if (blob_bytes < mstg_f16_attn_plan_bytes(C)) return mstg::fail_arg(MSTG_E_WORKSPACE, "f16 attn pack: blob too small");
     float* bias = (float*)blob;
     h16* wfrag = (h16*)((char*)blob + (size_t)4 * C * sizeof(float));
-    hipLaunchKernelGGL(f16_attn_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, wqkv, bqkv, wproj, bproj, C, wfrag, bias);
+    MSTG_LAUNCH(f16_attn_pack_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, wqkv, bqkv, wproj, bproj, C, wfrag, bias);
     MSTG_CHECK_LAUNCH("f16_attn_pack_kernel");
     return MSTG_OK;
 }
@@ -1416,7 +1416,7 @@ static int launch_attn_f16(const void* x, const float* in_stats, const void* blo
         attr_set = true;
     }
     dim3 grid(cdiv(W / 4, 4 * ATT_WPW), H / 4, N);
-    hipLaunchKernelGGL((attn_f16_kernel<C>), grid, dim3(256), lds, st, (const h16*)x, in_stats, wfrag, bias, (h16*)y, N, H, W);
+    MSTG_LAUNCH((attn_f16_kernel<C>), grid, dim3(256), lds, st, (const h16*)x, in_stats, wfrag, bias, (h16*)y, N, H, W);
     MSTG_CHECK_LAUNCH("attn_f16_kernel");
     return MSTG_OK;
 }

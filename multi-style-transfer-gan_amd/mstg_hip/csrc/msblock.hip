@@ -674,15 +674,15 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
             attr_set_p = true;
         }
         const int Sp = S * NG > ntiles ? ntiles : S * NG;  // one workgroup covers every input-channel chunk: keep the workgroup count
-        hipLaunchKernelGGL((wgrad_msp_kernel<CH>), dim3(Sp, 1, 1), dim3(256), ldsp, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
+        MSTG_LAUNCH((wgrad_msp_kernel<CH>), dim3(Sp, 1, 1), dim3(256), ldsp, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
         MSTG_CHECK_LAUNCH("wgrad_msp_kernel");
-        hipLaunchKernelGGL((wgrad_msp_reduce_kernel<CH>), dim3(cdiv(P::PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, Sp, accumulate);
+        MSTG_LAUNCH((wgrad_msp_reduce_kernel<CH>), dim3(cdiv(P::PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, Sp, accumulate);
         MSTG_CHECK_LAUNCH("wgrad_msp_reduce_kernel");
         return MSTG_OK;
     }
-    hipLaunchKernelGGL((wgrad_ms_kernel<CH>), dim3(S, NG, 1), dim3(256), lds, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
+    MSTG_LAUNCH((wgrad_ms_kernel<CH>), dim3(S, NG, 1), dim3(256), lds, st, x, dy, (float*)ws, N, H, W, tiles_x, tiles_y, ntiles);
     MSTG_CHECK_LAUNCH("wgrad_ms_kernel");
-    hipLaunchKernelGGL((wgrad_ms_reduce_kernel<CH>), dim3(cdiv(PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S, accumulate);
+    MSTG_LAUNCH((wgrad_ms_reduce_kernel<CH>), dim3(cdiv(PSTRIDE, 16)), dim3(256), 0, st, (const float*)ws, out, S, accumulate);
     MSTG_CHECK_LAUNCH("wgrad_ms_reduce_kernel");
     return MSTG_OK;
 }
@@ -706,7 +706,7 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
                 if (er != hipSuccess) return fail_launch(er, "hipFuncSetAttribute(ms_fwd4)");
                 attr4 = true;
             }
-            hipLaunchKernelGGL((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
+            MSTG_LAUNCH((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
             MSTG_CHECK_LAUNCH("ms_fwd4_kernel");
             return MSTG_OK;
         }
@@ -715,11 +715,11 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
     const size_t need = (size_t)(NCH * G::U * 256 + CH) * sizeof(float);
     if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_fwd: workspace too small");
     float* wp = (float*)ws;
-    hipLaunchKernelGGL((ms_pack_fwd_kernel<CH>), dim3(cdiv(NCH * G::U * 256 + CH, 256)), dim3(256), 0, st, prm, wp);
+    MSTG_LAUNCH((ms_pack_fwd_kernel<CH>), dim3(cdiv(NCH * G::U * 256 + CH, 256)), dim3(256), 0, st, prm, wp);
     MSTG_CHECK_LAUNCH("ms_pack_fwd_kernel");
     const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
     const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
-    hipLaunchKernelGGL((ms_fwd_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, (const float*)wp, y, N, H, W, tiles_x,
+    MSTG_LAUNCH((ms_fwd_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, (const float*)wp, y, N, H, W, tiles_x,
                        tiles_y);
     MSTG_CHECK_LAUNCH("ms_fwd_kernel");
     return MSTG_OK;
@@ -736,11 +736,11 @@ static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, const float*
     const size_t need = ms_dgrad_ws_floats<CH>() * sizeof(float);
     if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_dgrad: workspace too small");
     float* wp = (float*)ws;
-    hipLaunchKernelGGL((ms_pack_dgrad_kernel<CH>), dim3(cdiv((int)ms_dgrad_ws_floats<CH>(), 1024)), dim3(256), 0, st, prm, wp);
+    MSTG_LAUNCH((ms_pack_dgrad_kernel<CH>), dim3(cdiv((int)ms_dgrad_ws_floats<CH>(), 1024)), dim3(256), 0, st, prm, wp);
     MSTG_CHECK_LAUNCH("ms_pack_dgrad_kernel");
     const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
     const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
-    hipLaunchKernelGGL((ms_dgrad_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, dy, (const float*)wp, dres, dx, N, H, W,
+    MSTG_LAUNCH((ms_dgrad_kernel<CH>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, dy, (const float*)wp, dres, dx, N, H, W,
                        tiles_x, tiles_y);
     MSTG_CHECK_LAUNCH("ms_dgrad_kernel");
     return MSTG_OK;

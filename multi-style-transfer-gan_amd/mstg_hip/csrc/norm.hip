@@ -290,11 +290,11 @@ extern "C" int mstg_norm_act_fwd(const float* x, const float* residual, float* y
     const int rows = 256 / (C / 4);
     dim3 grid(g.split, N);
     if (batch_stats != 2) {
-        hipLaunchKernelGGL((norm_partial_kernel<false>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr, nullptr,
+        MSTG_LAUNCH((norm_partial_kernel<false>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr, nullptr,
                            gamma, beta, (float*)workspace, g, act, batch_stats);
         MSTG_CHECK_LAUNCH("norm_partial_kernel");
     }
-    hipLaunchKernelGGL((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats,
+    MSTG_LAUNCH((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats,
                        gamma, beta, running_mean, running_var, nullptr, nullptr, (const float*)workspace, g, act, batch_stats, g.split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel");
     return MSTG_OK;
@@ -312,10 +312,10 @@ extern "C" int mstg_norm_act_bwd(const float* x, const float* stats, const float
     hipStream_t st = (hipStream_t)stream;
     const int rows = 256 / (C / 4);
     dim3 grid(g.split, N);
-    hipLaunchKernelGGL((norm_partial_kernel<true>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, dy, stats, gamma, beta,
+    MSTG_LAUNCH((norm_partial_kernel<true>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, dy, stats, gamma, beta,
                        (float*)workspace, g, act, batch_stats);
     MSTG_CHECK_LAUNCH("norm_partial_kernel<bwd>");
-    hipLaunchKernelGGL((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx,
+    MSTG_LAUNCH((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx,
                        const_cast<float*>(stats), gamma, beta, nullptr, nullptr, dgamma, dbeta, (const float*)workspace, g, act,
                        batch_stats, g.split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
@@ -332,10 +332,10 @@ extern "C" int mstg_norm_stats(const float* x, float* stats, int N, int HW, int 
     if (workspace_bytes < mstg_norm_workspace_bytes(N, HW, C)) return fail_arg(MSTG_E_WORKSPACE, "norm_stats: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int rows = 256 / (C / 4);
-    hipLaunchKernelGGL((norm_partial_kernel<false>), dim3(g.split, N), dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr,
+    MSTG_LAUNCH((norm_partial_kernel<false>), dim3(g.split, N), dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr,
                        nullptr, nullptr, nullptr, (float*)workspace, g, MSTG_ACT_NONE, 0);
     MSTG_CHECK_LAUNCH("norm_partial_kernel");
-    hipLaunchKernelGGL(norm_stats_kernel, dim3(N), dim3(256), 0, st, x, (const float*)workspace, stats, g);
+    MSTG_LAUNCH(norm_stats_kernel, dim3(N), dim3(256), 0, st, x, (const float*)workspace, stats, g);
     MSTG_CHECK_LAUNCH("norm_stats_kernel");
     return MSTG_OK;
 }
@@ -348,7 +348,7 @@ extern "C" int mstg_norm_bwd_apply(const float* x, const float* stats, const flo
     if (!x || !stats || !dy || !sums || !dx) return fail_arg(MSTG_E_BADARG, "norm_bwd_apply: null pointer");
     if (sums_split < 1) return fail_arg(MSTG_E_BADARG, "norm_bwd_apply: sums_split must be >= 1");
     const NormGeom g = norm_geom(N, HW, C);
-    hipLaunchKernelGGL((norm_apply_kernel<true>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, dy,
+    MSTG_LAUNCH((norm_apply_kernel<true>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, dy,
                        nullptr, dx, const_cast<float*>(stats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums, g, act, 0, sums_split);
     MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
     return MSTG_OK;
@@ -362,7 +362,7 @@ extern "C" int mstg_norm_apply_fwd(const float* x, const float* stats, const flo
     if (!x || !stats || !y) return fail_arg(MSTG_E_BADARG, "norm_apply_fwd: null pointer");
     if (act == MSTG_ACT_TANH) return fail_arg(MSTG_E_UNSUPPORTED, "norm_apply_fwd: tanh epilogue not supported");
     const NormGeom g = norm_geom(N, HW, C);
-    hipLaunchKernelGGL((norm_apply_kernel<false>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, nullptr,
+    MSTG_LAUNCH((norm_apply_kernel<false>), dim3(g.split, N), dim3(256), (size_t)4 * C * sizeof(float), (hipStream_t)stream, x, nullptr,
                        residual, y, const_cast<float*>(stats), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, act, 3, 0);
     MSTG_CHECK_LAUNCH("norm_apply_kernel");
     return MSTG_OK;

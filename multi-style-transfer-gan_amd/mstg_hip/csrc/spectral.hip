@@ -256,17 +256,17 @@ extern "C" int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float*
         float* scratch = (float*)workspace;
         hipStream_t st = (hipStream_t)stream;
         if (training) {
-            hipLaunchKernelGGL(spectral_a_kernel, dim3(SN_G), dim3(256), 0, st, w, (const float*)u, scratch, M, K);
+            MSTG_LAUNCH(spectral_a_kernel, dim3(SN_G), dim3(256), 0, st, w, (const float*)u, scratch, M, K);
             MSTG_CHECK_LAUNCH("spectral_a_kernel");
         }
-        hipLaunchKernelGGL(spectral_b_kernel, dim3(SN_G), dim3(256), (size_t)(K + 64) * sizeof(float), st, w, v, scratch, M, K, eps, training, v_save);
+        MSTG_LAUNCH(spectral_b_kernel, dim3(SN_G), dim3(256), (size_t)(K + 64) * sizeof(float), st, w, v, scratch, M, K, eps, training, v_save);
         MSTG_CHECK_LAUNCH("spectral_b_kernel");
-        hipLaunchKernelGGL(spectral_c_kernel, dim3(SN_G), dim3(256), 0, st, w, u, (const float*)scratch, w_out, sigma, M, K, eps, training, u_save);
+        MSTG_LAUNCH(spectral_c_kernel, dim3(SN_G), dim3(256), 0, st, w, u, (const float*)scratch, w_out, sigma, M, K, eps, training, u_save);
         MSTG_CHECK_LAUNCH("spectral_c_kernel");
         return MSTG_OK;
     }
     const size_t lds = (size_t)(M + K + 64) * sizeof(float);
-    hipLaunchKernelGGL(spectral_norm_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, w, u, v, w_out, sigma, M, K, eps, training, u_save,
+    MSTG_LAUNCH(spectral_norm_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, w, u, v, w_out, sigma, M, K, eps, training, u_save,
                        v_save);
     MSTG_CHECK_LAUNCH("spectral_norm_fwd_kernel");
     return MSTG_OK;
@@ -281,13 +281,13 @@ extern "C" int mstg_spectral_norm_bwd(const float* dwn, const float* w, const fl
             return fail_arg(MSTG_E_WORKSPACE, "spectral_norm_bwd: workspace too small");
         float* scratch = (float*)workspace;
         hipStream_t st = (hipStream_t)stream;
-        hipLaunchKernelGGL(spectral_bwd_a_kernel, dim3(SN_G), dim3(256), 0, st, dwn, w, scratch, M, K);
+        MSTG_LAUNCH(spectral_bwd_a_kernel, dim3(SN_G), dim3(256), 0, st, dwn, w, scratch, M, K);
         MSTG_CHECK_LAUNCH("spectral_bwd_a_kernel");
-        hipLaunchKernelGGL(spectral_bwd_b_kernel, dim3(SN_G), dim3(256), 0, st, dwn, u, v, sigma, (const float*)scratch, dw, M, K, accumulate);
+        MSTG_LAUNCH(spectral_bwd_b_kernel, dim3(SN_G), dim3(256), 0, st, dwn, u, v, sigma, (const float*)scratch, dw, M, K, accumulate);
         MSTG_CHECK_LAUNCH("spectral_bwd_b_kernel");
         return MSTG_OK;
     }
-    hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dwn, w, u, v, sigma, dw, M, K, accumulate);
+    MSTG_LAUNCH(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dwn, w, u, v, sigma, dw, M, K, accumulate);
     MSTG_CHECK_LAUNCH("spectral_norm_bwd_kernel");
     return MSTG_OK;
 }

@@ -201,7 +201,7 @@ extern "C" int mstg_maxpool2x2_fwd(const float* x, float* y, unsigned char* idx,
     if (C & 3) return fail_arg(MSTG_E_ALIGN, "maxpool_fwd: C must be a multiple of 4");
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
     const int nb = (int)(cdivz(total, 256) > 4096 ? 4096 : cdivz(total, 256));
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C / 4);
+    MSTG_LAUNCH(maxpool_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W, C / 4);
     MSTG_CHECK_LAUNCH("maxpool_fwd_kernel");
     return MSTG_OK;
 }
@@ -212,7 +212,7 @@ extern "C" int mstg_maxpool2x2_bwd(const float* dy, const unsigned char* idx, fl
     if (C & 3) return fail_arg(MSTG_E_ALIGN, "maxpool_bwd: C must be a multiple of 4");
     const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
     const int nb = (int)(cdivz(total, 256) > 4096 ? 4096 : cdivz(total, 256));
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C / 4);
+    MSTG_LAUNCH(maxpool_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W, C / 4);
     MSTG_CHECK_LAUNCH("maxpool_bwd_kernel");
     return MSTG_OK;
 }
@@ -233,9 +233,9 @@ extern "C" int mstg_gram_fwd(const float* f, float* g, int N, int HW, int C, flo
     pps = cdiv(pps, GP) * GP;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((C / 16) * cdiv(C, 64), S, N);
-    hipLaunchKernelGGL(gram_fwd_kernel, grid, dim3(256), 0, st, f, (float*)workspace, HW, C, S, pps);
+    MSTG_LAUNCH(gram_fwd_kernel, grid, dim3(256), 0, st, f, (float*)workspace, HW, C, S, pps);
     MSTG_CHECK_LAUNCH("gram_fwd_kernel");
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(cdiv(C * C, 256), N), dim3(256), 0, st, (const float*)workspace, g, S, C * C, scale);
+    MSTG_LAUNCH(gram_reduce_kernel, dim3(cdiv(C * C, 256), N), dim3(256), 0, st, (const float*)workspace, g, S, C * C, scale);
     MSTG_CHECK_LAUNCH("gram_reduce_kernel");
     return MSTG_OK;
 }
@@ -245,7 +245,7 @@ extern "C" int mstg_gram_bwd(const float* f, const float* dg, float* df, int N, 
     if (N <= 0 || HW <= 0 || C <= 0) return fail_arg(MSTG_E_BADARG, "gram_bwd: empty tensor");
     if (C % 16) return fail_arg(MSTG_E_ALIGN, "gram_bwd: C must be a multiple of 16");
     dim3 grid(cdiv(HW, GP), cdiv(C, 64), N);
-    hipLaunchKernelGGL(gram_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, dg, df, HW, C, scale);
+    MSTG_LAUNCH(gram_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, f, dg, df, HW, C, scale);
     MSTG_CHECK_LAUNCH("gram_bwd_kernel");
     return MSTG_OK;
 }

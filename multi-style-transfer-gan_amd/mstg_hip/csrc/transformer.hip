@@ -438,11 +438,11 @@ static int launch_flash(int pass, const float* qkv, float* out, float* lse, cons
     dim3 grid(cdiv(L, FA_TQ), heads, N);
     if (pass == 0) {
         const size_t lds = (size_t)(FA_TK * C::SK + FA_TK * C::SV) * sizeof(float);
-        hipLaunchKernelGGL((flash_fwd_kernel<D>), grid, dim3(256), lds, st, qkv, out, lse, N, L, heads, scale);
+        MSTG_LAUNCH((flash_fwd_kernel<D>), grid, dim3(256), lds, st, qkv, out, lse, N, L, heads, scale);
         MSTG_CHECK_LAUNCH("flash_fwd_kernel");
     } else {
         const size_t lds1 = (size_t)(2 * FA_TK * C::SK + FA_TK * C::SV) * sizeof(float);
-        hipLaunchKernelGGL((flash_bwd_dq_kernel<D>), grid, dim3(256), lds1, st, qkv, d_o, (const float*)lse, delta, dqkv, N, L, heads, scale);
+        MSTG_LAUNCH((flash_bwd_dq_kernel<D>), grid, dim3(256), lds1, st, qkv, d_o, (const float*)lse, delta, dqkv, N, L, heads, scale);
         MSTG_CHECK_LAUNCH("flash_bwd_dq_kernel");
         const size_t lds2 = (size_t)(2 * FA_TQ * C::SK + 2 * FA_TQ * C::SV + 2 * FA_TQ) * sizeof(float);
         static bool attr_set = false;
@@ -450,7 +450,7 @@ static int launch_flash(int pass, const float* qkv, float* out, float* lse, cons
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flash_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             attr_set = true;
         }
-        hipLaunchKernelGGL((flash_bwd_dkv_kernel<D>), grid, dim3(256), lds2, st, qkv, d_o, (const float*)lse, delta, dqkv, N, L, heads, scale);
+        MSTG_LAUNCH((flash_bwd_dkv_kernel<D>), grid, dim3(256), lds2, st, qkv, d_o, (const float*)lse, delta, dqkv, N, L, heads, scale);
         MSTG_CHECK_LAUNCH("flash_bwd_dkv_kernel");
     }
     return MSTG_OK;
@@ -473,7 +473,7 @@ extern "C" int mstg_structure_map(const float* img, float* out, int N, int H, in
     const size_t total = (size_t)N * (H / 4) * (W / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(structure_map_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W);
+    MSTG_LAUNCH(structure_map_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, out, N, H, W);
     MSTG_CHECK_LAUNCH("structure_map_kernel");
     return MSTG_OK;
 }
@@ -484,7 +484,7 @@ extern "C" int mstg_ln_mod_fwd(const float* x, const float* gamma, const float* 
     if ((gmod == nullptr) != (bmod == nullptr)) return fail_arg(MSTG_E_BADARG, "ln_mod_fwd: gmod and bmod come together");
     if (N <= 0 || L <= 0 || dim <= 0 || dim % 4 || dim > 64 * LN_MAXC) return fail_arg(MSTG_E_ALIGN, "ln_mod: dim must be a multiple of 4, <= 256");
     const size_t T = (size_t)N * L;
-    hipLaunchKernelGGL(ln_mod_fwd_kernel, dim3((unsigned)((T + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gmod, bmod, y,
+    MSTG_LAUNCH(ln_mod_fwd_kernel, dim3((unsigned)((T + 15) / 16)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, gmod, bmod, y,
                        stats, N, L, dim, eps);
     MSTG_CHECK_LAUNCH("ln_mod_fwd_kernel");
     return MSTG_OK;
@@ -515,10 +515,10 @@ extern "C" int mstg_ln_mod_bwd(const float* x, const float* stats, const float* 
     int chunk;
     const int nchunk = ln_chunks(L, &chunk);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3(nchunk, N), dim3(256), (size_t)16 * 4 * dim * sizeof(float), st, x, stats, gamma, beta, gmod, dy,
+    MSTG_LAUNCH(ln_mod_bwd_kernel, dim3(nchunk, N), dim3(256), (size_t)16 * 4 * dim * sizeof(float), st, x, stats, gamma, beta, gmod, dy,
                        dx, (float*)workspace, N, L, dim, chunk, nchunk);
     MSTG_CHECK_LAUNCH("ln_mod_bwd_kernel");
-    hipLaunchKernelGGL(ln_mod_reduce_kernel, dim3(cdiv(dim, 64)), dim3(64), 0, st, (const float*)workspace, N, nchunk, dim, dgamma, dbeta, dgmod,
+    MSTG_LAUNCH(ln_mod_reduce_kernel, dim3(cdiv(dim, 64)), dim3(64), 0, st, (const float*)workspace, N, nchunk, dim, dgamma, dbeta, dgmod,
                        dbmod, accumulate);
     MSTG_CHECK_LAUNCH("ln_mod_reduce_kernel");
     return MSTG_OK;
@@ -546,7 +546,7 @@ extern "C" int mstg_flash_attn_bwd(const float* qkv, const float* out, const flo
     const size_t total = (size_t)N * heads * L;
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(flash_delta_kernel, dim3(grid), dim3(256), 0, st, out, d_out, delta_ws, N, L, heads, D);
+    MSTG_LAUNCH(flash_delta_kernel, dim3(grid), dim3(256), 0, st, out, d_out, delta_ws, N, L, heads, D);
     MSTG_CHECK_LAUNCH("flash_delta_kernel");
     switch (D) {
         case 8: return launch_flash<8>(1, qkv, nullptr, const_cast<float*>(lse), d_out, delta_ws, dqkv, N, L, heads, scale, st);

@@ -106,7 +106,7 @@ class _PackedAttention:
     def __call__(self, x, in_stats=None):
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed(f"attn_f16_kernel<{Cn}>", 16.0 * Cn * Cn * N * H * W, 2.0 * 2 * x.numel(), lambda: _lib.check(
+        _timed(f"attn_f16_kernel<{Cn}>", 12.0 * Cn * Cn * N * H * W, 2.0 * 2 * x.numel(), lambda: _lib.check(
             _lib.load().mstg_f16_attn_fwd(_p(x), _p(in_stats), _p(self.blob), _p(y), N, H, W, Cn, _stream()), "mstg_f16_attn_fwd"),
             f"N{N} {H}x{W} C{Cn}")
         return y

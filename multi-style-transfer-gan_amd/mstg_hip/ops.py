@@ -89,32 +89,100 @@ def _grad_slot(p):
 
 
 class KernelTimer:
-    """Opt-in per-launch timing with HIP events on the launch stream (torch's current stream), used by bench.py for the
-    roofline figure.  Each record: (kernel symbol, start event, end event, algorithmic flops, algorithmic bytes)."""
+    """Opt-in per-KERNEL timing for bench.py's roofline figure.  The library brackets every kernel it launches with two HIP events on
+    the launch stream (mstg_prof_*, csrc/runtime.hip) and reports the symbol rocprofv3 would print; this class adds the
+    ALGORITHMIC work of each C-ABI call (multiply-add = 2 FLOP, no recompute, no padding; every tensor read once and
+    written once) and books it on the kernel that does the call's arithmetic.  Helper launches of a call (filter packing, slab
+    reduction, statistics finalize) and launches outside any `_timed` call appear under their own symbols with zero algorithmic
+    work: their time is overhead and is shown as such."""
     enabled = False
-    records = []
+    calls = []  # (label, first record, one-past-last record, flops, bytes, detail, split)
 
     @classmethod
-    def summary(cls, detail=False):
-        """{symbol: dict(launches, ms, flops, bytes)} -- call after torch.cuda.synchronize()."""
+    def start(cls):
+        _lib.check(_lib.load().mstg_prof_enable(1), "mstg_prof_enable")
+        cls.enabled, cls.calls = True, []
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        _lib.load().mstg_prof_enable(0)
+
+    @classmethod
+    def kernels(cls):
+        """[(symbol, milliseconds)] of every launch since start(), in launch order (waits for the events)."""
+        lib = _lib.load()
+        out, buf, ms = [], C.create_string_buffer(512), C.c_float()
+        for i in range(lib.mstg_prof_count()):
+            _lib.check(lib.mstg_prof_get(i, buf, 512, C.byref(ms)), "mstg_prof_get")
+            out.append((buf.value.decode(), float(ms.value)))
+        return out
+
+    @staticmethod
+    def _owner(label, names_ms):
+        """Index (within a call's launches) of the kernel the call's algorithmic work belongs to: the launch whose symbol starts
+        with the label's kernel name, else the longest launch."""
+        stem = label.split("<")[0]
+        hits = [k for k, (nm, _) in enumerate(names_ms) if nm.split("<")[0] == stem]
+        if hits:
+            return max(hits, key=lambda k: names_ms[k][1])
+        return max(range(len(names_ms)), key=lambda k: names_ms[k][1])
+
+    @classmethod
+    def summary(cls, detail=False, by_call=False):
+        """{kernel symbol: dict(launches, ms, flops, bytes)} (by_call=True: {call label: dict(calls, ms, flops, bytes, kernels)})."""
+        ks = cls.kernels()
         out = {}
-        for sym, s, e, fl, by, det in cls.records:
-            r = out.setdefault(f"{sym} {det}" if detail else sym, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
-            r["launches"] += 1
-            r["ms"] += s.elapsed_time(e)
-            r["flops"] += fl
-            r["bytes"] += by
+
+        def row(key):
+            return out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        covered = [False] * len(ks)
+        for label, c0, c1, fl, by, det, split in cls.calls:
+            mine = ks[c0:c1]
+            if not mine:
+                continue
+            for k in range(c0, c1):
+                covered[k] = True
+            if by_call:
+                r = row(f"{label} {det}" if detail else label)
+                r["launches"] += 1
+                r["ms"] += sum(m for _, m in mine)
+                r["flops"] += fl
+                r["bytes"] += by
+                r.setdefault("kernels", set()).update(nm for nm, _ in mine)
+                continue
+            shares = {}
+            if split:
+                for k, (nm, _) in enumerate(mine):
+                    for stem, (sfl, sby) in split.items():
+                        if nm.split("<")[0] == stem.split("<")[0] and (stem.find("<") < 0 or nm.startswith(stem)):
+                            shares[k] = (sfl, sby)
+            if not shares:
+                shares[cls._owner(label, mine)] = (fl, by)
+            for k, (nm, m) in enumerate(mine):
+                r = row(f"{nm} {det}" if detail else nm)
+                r["launches"] += 1
+                r["ms"] += m
+                sfl, sby = shares.get(k, (0.0, 0.0))
+                r["flops"] += sfl
+                r["bytes"] += sby
+        for k, (nm, m) in enumerate(ks):
+            if not covered[k]:
+                r = row(nm)
+                r["launches"] += 1
+                r["ms"] += m
         return out
 
 
-def _timed(sym, flops, nbytes, fn, detail=""):
+def _timed(sym, flops, nbytes, fn, detail="", split=None):
+    """Run one C-ABI call; with the timer on, remember which of the library's launch records it produced and its algorithmic work.
+    split = {kernel symbol stem: (flops, bytes)} books the work on several kernels of the call (two-kernel passes)."""
     if not KernelTimer.enabled:
         return fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
+    lib = _lib.load()
+    c0 = lib.mstg_prof_count()
     fn()
-    e.record()
-    KernelTimer.records.append((sym, s, e, float(flops), float(nbytes), detail))
+    KernelTimer.calls.append((sym, c0, lib.mstg_prof_count(), float(flops), float(nbytes), detail, split))
 
 
 def _conv_detail(tag, d: ConvDesc):
@@ -316,7 +384,7 @@ class MSFusionFn(torch.autograd.Function):
         Cout = w.shape[0]
         stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=cat.device)
         ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
-        _timed("norm_act_fwd", 0, 4 * cat.numel(), lambda: _lib.check(
+        _timed("norm_partial_kernel<false>", 0, 4 * cat.numel(), lambda: _lib.check(
             lib.mstg_norm_stats(_p(cat), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
         ystats = torch.empty((N, Cout, 2), dtype=torch.float32, device=cat.device)  # (mean, rstd) of y from the epilogue
@@ -344,7 +412,7 @@ class MSFusionFn(torch.autograd.Function):
             conv_dgrad_raw(d, dy, w, dz)  # gradient w.r.t. the normalised concat
             dcat = torch.empty_like(cat)
             ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
-            _timed("norm_act_bwd", 0, 4 * cat.numel() * 5, lambda: _lib.check(
+            _timed("norm_apply_kernel<true>", 0, 4 * cat.numel() * 3, lambda: _lib.check(
                 lib.mstg_norm_act_bwd(_p(cat), _p(stats), _p(dz), _p(dcat), N, H * W, Cn, ACT_RELU, 0, None, None, None, None, _p(ws),
                                       ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
         if ctx.needs_input_grad[1]:
@@ -471,7 +539,7 @@ class InstNormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
-        _timed("norm_act_fwd", 0, 4 * x.numel() * (3 if residual is None else 4), lambda: _lib.check(
+        _timed("norm_apply_kernel<false>", 0, 4 * x.numel() * (2 if residual is None else 3), lambda: _lib.check(
             lib.mstg_norm_act_fwd(_p(x), _p(residual), _p(y), _p(stats), N, H * W, Cn, act, 0, None, None, None, None,
                                   _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_fwd"))
         ctx.act, ctx.has_res = act, residual is not None
@@ -488,7 +556,7 @@ class InstNormActFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
-            _timed("norm_act_bwd", 0, 4 * x.numel() * 5, lambda: _lib.check(
+            _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
                 lib.mstg_norm_act_bwd(_p(x), _p(stats), _p(dy), _p(dx), N, H * W, Cn, ctx.act, 0, None, None, None, None,
                                       _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
         return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None
@@ -509,7 +577,7 @@ class InstNormApplyFn(torch.autograd.Function):
         residual = None if residual is None else _req(residual, "norm residual")
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed("norm_act_fwd", 0, 4 * x.numel() * (2 if residual is None else 3), lambda: _lib.check(
+        _timed("norm_apply_kernel<false>", 0, 4 * x.numel() * (2 if residual is None else 3), lambda: _lib.check(
             lib.mstg_norm_apply_fwd(_p(x), _p(stats), _p(residual), _p(y), N, H * W, Cn, act, _stream()), "mstg_norm_apply_fwd"))
         ctx.act, ctx.has_res = act, residual is not None
         ctx.save_for_backward(x, stats)
@@ -591,7 +659,7 @@ class WindowAttnCoreFn(torch.autograd.Function):
         N, H, W, C3 = qkv.shape
         dqkv = torch.empty_like(qkv)
         Cn = C3 // 3
-        _timed(_attn_core_symbol('bwd', Cn), 12 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
+        _timed(_attn_core_symbol('bwd', Cn), 8 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_core_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, _stream()), "mstg_window_attn_core_bwd"), detail=f"attn-core N{N} {H}x{W} C{Cn}")
         return dqkv
 
@@ -606,7 +674,7 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}, false>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_fwd_kernel<{Cn}, false>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_fwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_fwd"))
         ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj)
@@ -621,7 +689,7 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}, false>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_bwd_kernel<{Cn}, false>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_bwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), _p(flat), N, H, W, Cn, _p(ws),
                                      ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
         c2 = Cn * Cn
@@ -644,10 +712,10 @@ class NormLocalAttentionFn(torch.autograd.Function):
         if stats is None:  # no producer epilogue delivered them: one pass over x
             stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=x.device)
             ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
-            _timed("norm_act_fwd", 0, 4 * x.numel(), lambda: _lib.check(
+            _timed("norm_partial_kernel<false>", 0, 4 * x.numel(), lambda: _lib.check(
                 lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}, true>", 16 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_fwd_kernel<{Cn}, true>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_norm_fwd"))
         ctx.save_for_backward(x, stats, wqkv, bqkv, wproj, bproj)
@@ -664,13 +732,13 @@ class NormLocalAttentionFn(torch.autograd.Function):
         S = lib.mstg_window_attn_norm_sums_split()
         sums = torch.empty((N, S, 2, Cn), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}, true>", 44 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_fused_bwd_kernel<{Cn}, true>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_bwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz), _p(flat),
                                           _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_norm_bwd"))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _timed("norm_act_bwd", 0, 4 * x.numel() * 3, lambda: _lib.check(
+            _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
                 lib.mstg_norm_bwd_apply(_p(x), _p(stats), _p(dz), _p(sums), S, _p(dx), N, H * W, Cn, ACT_RELU, _stream()),
                 "mstg_norm_bwd_apply"))
         c2 = Cn * Cn
@@ -1036,9 +1104,11 @@ class FlashAttnFn(torch.autograd.Function):
         D = C3 // 3 // heads
         dqkv = torch.empty_like(qkv)
         delta = torch.empty((N, heads, L), dtype=torch.float32, device=qkv.device)
-        _timed(f"flash_bwd_kernels<{D}>", 10.0 * N * heads * L * L * D, 4.0 * (2 * qkv.numel() + 2 * out.numel()), lambda: _lib.check(
+        _timed(f"flash_bwd_dkv_kernel<{D}>", 8.0 * N * heads * L * L * D, 4.0 * (2 * qkv.numel() + 2 * out.numel()), lambda: _lib.check(
             _lib.load().mstg_flash_attn_bwd(_p(qkv), _p(out), _p(lse), _p(d_out), _p(dqkv), _p(delta), N, L, heads, D, _stream()),
-            "mstg_flash_attn_bwd"), f"N{N} L{L} heads{heads} D{D}")
+            "mstg_flash_attn_bwd"), f"N{N} L{L} heads{heads} D{D}",
+            split={f"flash_bwd_dq_kernel<{D}>": (4.0 * N * heads * L * L * D, 4.0 * (qkv.numel() + out.numel())),
+                   f"flash_bwd_dkv_kernel<{D}>": (4.0 * N * heads * L * L * D, 4.0 * (qkv.numel() + out.numel()))})
         return dqkv, None
 
 
