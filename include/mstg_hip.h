@@ -69,6 +69,24 @@ typedef struct mstg_conv_desc {
     int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
 } mstg_conv_desc;
 
+/* Filter-pack caching.  mstg_conv2d_fwd / _fwd_norm / _dgrad and mstg_msblock_fwd / _dgrad begin by re-packing the filter into the
+ * caller's workspace (a ~5 us launch, ~170 of them per CycleGAN step).  The *_cached twins take workspace_packed: non-zero = "this
+ * workspace still holds what the SAME call (same descriptor, same pass, same weight VALUES) packed into it", and the pack launch is
+ * skipped.  Whether that is true is the caller's knowledge (weights change at optimizer.step(); mstg_hip/ops.py keeps one workspace
+ * per (layer, pass, stream) and a stamp of the weights' version); with workspace_packed = 0 they are the plain entry points. */
+int mstg_conv2d_fwd_cached(const mstg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
+                           size_t workspace_bytes, int workspace_packed, void* stream);
+int mstg_conv2d_fwd_norm_cached(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias,
+                                float* y, float* out_stats, void* workspace, size_t workspace_bytes, int workspace_packed, void* stream);
+int mstg_conv2d_dgrad_cached(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace, size_t workspace_bytes,
+                             int workspace_packed, void* stream);
+int mstg_msblock_fwd_cached(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                            const float* b3, const float* w4, const float* b4, float* y, int N, int H, int W, int CH, void* workspace,
+                            size_t workspace_bytes, int workspace_packed, void* stream);
+int mstg_msblock_dgrad_cached(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4, const float* dres,
+                              float* dx, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes, int workspace_packed,
+                              void* stream);
+
 /* name of the kernel a pass (0 forward, 1 dgrad, 2 wgrad) of this layer launches, as a profiler prints it (for reports) */
 const char* mstg_conv2d_kernel_name(const mstg_conv_desc* d, int pass);
 /* workspace of fwd and dgrad: room for the filter re-packed into the order the kernel stages it (a few 100 KB at most) */
@@ -311,6 +329,13 @@ int mstg_u8_to_tensor(const unsigned char* src, int sh, int sw, int y0, int x0, 
                       float* mask_out, unsigned long long grid, int use_mask, void* stream);
 /* (y + 1) / 2 -> clamp(0, 1) -> * 255 -> uint8: y (3, H, W) fp32 -> dst (H, W, 3) (batch_process_images.py:213-217) */
 int mstg_tensor_to_u8(const float* y, int H, int W, unsigned char* dst, void* stream);
+/* Per-pixel blend of the letterboxed original with the styled image (uint8 HWC both), bit-exact with numpy's float64 evaluation:
+ * out = clip(orig * (1 - w) + styled * w, 0, 255).astype(uint8).  weight_map == NULL: w = strength everywhere and
+ * one_minus_strength is the caller's double 1 - strength (process_local_style mode 'simple', batch_process_images.py:304-312);
+ * else w = weight_map[y][x] (float64, H x W: the 'enhanced' / 'advanced' weight-map blend of :340-342 / :386-387 followed by the
+ * clip + cast of :352 -- the masks themselves come from cv2 / scipy on the host and are not part of this library). */
+int mstg_blend_u8(const unsigned char* orig, const unsigned char* styled, double one_minus_strength, double strength,
+                  const double* weight_map /*nullable*/, unsigned char* out, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BUILD-DEFINED StructuralTransformerBlock pieces.  The reference imports the class from a file its snapshot does not contain

@@ -41,6 +41,11 @@ SIGNATURES = {
     "mstg_conv2d_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_conv2d_dgrad": (_i, [_dp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "mstg_conv2d_fwd_cached": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
+    "mstg_conv2d_fwd_norm_cached": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
+    "mstg_conv2d_dgrad_cached": (_i, [_dp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
+    "mstg_msblock_fwd_cached": (_i, [_fp] * 10 + [_i, _i, _i, _i, _vp, _sz, _i, _vp]),
+    "mstg_msblock_dgrad_cached": (_i, [_fp] * 7 + [_i, _i, _i, _i, _vp, _sz, _i, _vp]),
     "mstg_conv2d_wgrad_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_wgrad": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_norm_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -116,6 +121,7 @@ SIGNATURES = {
     "mstg_paste_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _vp]),
     "mstg_u8_to_tensor": (_i, [_vp, _i, _i, _i, _i, _i, _i, _fp, _fp, _fp, C.c_ulonglong, _i, _vp]),
     "mstg_tensor_to_u8": (_i, [_fp, _i, _i, _vp, _vp]),
+    "mstg_blend_u8": (_i, [_vp, _vp, C.c_double, C.c_double, _vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

@@ -716,6 +716,17 @@ static int fused_blocks(int N, int H, int W) {
     return nwin < 2048 ? nwin : 2048;  // one-wave workgroups: 8 per CU
 }
 
+// The register-resident kernels of csrc/attention_reg.hip (round 3): the default; MSTG_ATTN_REG=0 selects the LDS-tile kernels above.
+int attn_reg_bwd_blocks(int C);
+int attn_reg_fwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
+                 float* y, int N, int H, int W, hipStream_t st);
+int attn_reg_bwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* dy,
+                 float* dx, float* partial, float* nsum, int kblk, int nblocks, int N, int H, int W, hipStream_t st);
+static bool attn_reg_on() {
+    const char* e = env_get(ENV_ATTN_REG);
+    return !(e && e[0] == '0');
+}
+
 // in_stats != nullptr: x is the raw tensor in front of InstanceNorm + ReLU; backward then also fills norm_sums[N][2][C]
 // (workspace layout: [weight-gradient slabs: nb * SLAB][nsum rows: N * nb * 2C])
 template <int C>
@@ -724,6 +735,23 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
                         const float* in_stats = nullptr, float* norm_sums = nullptr) {
     typedef FusedTiles<C> F;
     const int nb = fused_blocks(N, H, W);
+    if (attn_reg_on()) {
+        if (!bwd) return attn_reg_fwd(C, x, in_stats, wqkv, bqkv, wp, bp, out, N, H, W, st);
+        // slabs: one per workgroup of four waves, never more workgroups than runs / 4 (and so never more than the nb slabs the
+        // workspace was sized for); the nsum rows sit behind the nb-slab region as before
+        const int kblk = in_stats ? norm_run_len(H, W) : 1, R = (H / 4) * (W / 4) / kblk, nrun = N * R;
+        int nbr = attn_reg_bwd_blocks(C);
+        if (nbr > cdiv(nrun, 4)) nbr = cdiv(nrun, 4);
+        float* nsum = partial + (size_t)nb * F::SLAB;
+        if (int rc = attn_reg_bwd(C, x, in_stats, wqkv, bqkv, wp, dy, out, partial, in_stats ? nsum : nullptr, kblk, nbr, N, H, W, st)) return rc;
+        if (in_stats) {
+            MSTG_LAUNCH(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
+            MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
+        }
+        MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nbr, F::SLAB);
+        MSTG_CHECK_LAUNCH("slab_reduce_kernel");
+        return MSTG_OK;
+    }
     if (!bwd) {
         if (in_stats)
             MSTG_LAUNCH((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,

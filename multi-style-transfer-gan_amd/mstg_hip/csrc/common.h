@@ -43,13 +43,24 @@ void prof_end(hipStream_t st);
         if (prof__) mstg::prof_end((hipStream_t)(st));                             \
     } while (0)
 
+// ---- caller-cached filter packs ----------------------------------------------------------------------------------------------
+// Every convolution launch re-packs its filter into the caller's workspace first (a ~5 us kernel).  The *_cached entry points let
+// a caller that KNOWS the workspace still holds the pack of the same weights (same descriptor, same pass) skip that launch:
+// they raise this thread-local flag around the plain entry point, and every pack site tests it.  Not library state: it is false
+// outside a *_cached call.
+extern thread_local bool t_ws_packed;
+#define MSTG_PACK_LAUNCH(...)                      \
+    do {                                           \
+        if (!mstg::t_ws_packed) MSTG_LAUNCH(__VA_ARGS__); \
+    } while (0)
+
 // ---- runtime switches ------------------------------------------------------------------------------------------------
 // The MSTG_* environment switches are read ONCE, when the library is loaded, and again on
 // mstg_env_refresh(): a train step makes ~1400 launches and each planner used to call getenv() several times per launch.
 enum EnvKnob {
     ENV_ATTN_BLK4, ENV_ATTN_BLK64, ENV_WGRAD_1X1, ENV_WGRAD_TS_MAXCH, ENV_WGRAD_PLAIN, ENV_WGRAD_OLD, ENV_NO_DPACK, ENV_IGEMM,
     ENV_STREAM, ENV_PF, ENV_WGLOB, ENV_HEAVY_PER_CU, ENV_DBG, ENV_DBG_LDS_KB, ENV_MS_WGRAD_PACKED, ENV_MS_FWD4, ENV_NO_PACK_CACHE,
-    ENV_P32, ENV_P32_TH, ENV_P32_WLDS, ENV_P32_DBG, ENV_P32_OCC,
+    ENV_P32, ENV_P32_TH, ENV_P32_WLDS, ENV_P32_DBG, ENV_P32_OCC, ENV_ATTN_REG,
     ENV_COUNT
 };
 const char* env_get(EnvKnob k);  // value as of the last refresh, nullptr when unset (runtime.hip)

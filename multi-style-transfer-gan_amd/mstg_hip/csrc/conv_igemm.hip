@@ -979,7 +979,7 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
 static int launch_pack(IGemmArgs& a, const IGemmPlan& p, float* wp, hipStream_t st) {
     const int npack = p.ncls * p.nchunks * a.ntaps * p.CoP * p.CK;
     const int nb = cdiv(npack, 256) > 256 ? 256 : cdiv(npack, 256);
-    MSTG_LAUNCH(pack_filter_kernel, dim3(nb), dim3(256), 0, st, a, wp, p.CK, p.CoP, p.nchunks, p.ncls);
+    MSTG_PACK_LAUNCH(pack_filter_kernel, dim3(nb), dim3(256), 0, st, a, wp, p.CK, p.CoP, p.nchunks, p.ncls);
     MSTG_CHECK_LAUNCH("pack_filter_kernel");
     return MSTG_OK;
 }
@@ -1195,6 +1195,30 @@ extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const
     if (int rc = fill_dgrad_args(d, a)) return rc;
     a.x = dy; a.y = dx; a.w = w; a.bias = nullptr;
     return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// ---- the same entry points for a caller that caches filter packs (common.h: t_ws_packed) -------------------------------------------
+namespace {
+struct PackedScope {
+    explicit PackedScope(int packed) { mstg::t_ws_packed = packed != 0; }
+    ~PackedScope() { mstg::t_ws_packed = false; }
+};
+}  // namespace
+extern "C" int mstg_conv2d_fwd_cached(const mstg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, void* workspace,
+                                      size_t workspace_bytes, int workspace_packed, void* stream) {
+    PackedScope scope(workspace_packed);
+    return mstg_conv2d_fwd(d, x, w, bias, y, workspace, workspace_bytes, stream);
+}
+extern "C" int mstg_conv2d_fwd_norm_cached(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias,
+                                           float* y, float* out_stats, void* workspace, size_t workspace_bytes, int workspace_packed,
+                                           void* stream) {
+    PackedScope scope(workspace_packed);
+    return mstg_conv2d_fwd_norm(d, x, in_stats, w, bias, y, out_stats, workspace, workspace_bytes, stream);
+}
+extern "C" int mstg_conv2d_dgrad_cached(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, void* workspace,
+                                        size_t workspace_bytes, int workspace_packed, void* stream) {
+    PackedScope scope(workspace_packed);
+    return mstg_conv2d_dgrad(d, dy, w, dx, workspace, workspace_bytes, stream);
 }
 
 // kernel symbol (as rocprofv3 prints it, without namespace/arguments) a forward (0) / dgrad (1) call would launch

@@ -679,7 +679,7 @@ static int launch_p32d(const IGemmArgs& g, void* workspace, size_t workspace_byt
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32d: tensor too large for the 32-bit tile arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    MSTG_LAUNCH(p32d_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_PACK_LAUNCH(p32d_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32d_pack_kernel");
     size_t patch = (size_t)p.PH * p.PW * p.pixstride;
     if (patch < (size_t)4 * 256 * (TH / 4) * sizeof(float)) patch = (size_t)4 * 256 * (TH / 4) * sizeof(float);  // the exchange tiles live there too
@@ -785,7 +785,7 @@ static int launch_p32i(const IGemmArgs& g, void* workspace, size_t workspace_byt
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32i: tensor too large for the 32-bit tile arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    MSTG_LAUNCH(p32i_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_PACK_LAUNCH(p32i_pack_kernel, dim3(16), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32i_pack_kernel");
     const size_t lds = (size_t)P32I_MAX_STEPS * 16 + (size_t)p.nsteps * 1024 + (size_t)p.PH * p.PW * 16;
     static int occ = 0;
@@ -989,7 +989,7 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
         return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: tensor too large for the 32-bit tile / offset arithmetic");
     p.m_ntile = magic_u32((unsigned)(a.tiles_x * a.tiles_y));
     p.m_tx = magic_u32((unsigned)a.tiles_x);
-    MSTG_LAUNCH(p32_pack_kernel, dim3(32), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
+    MSTG_PACK_LAUNCH(p32_pack_kernel, dim3(32), dim3(256), 0, st, p, g.w, g.bias, g.w_so, g.w_sr, g.Co, g.Cr, (float*)a.wpk, (float*)a.bias);
     MSTG_CHECK_LAUNCH("p32_pack_kernel");
     size_t lds = P32_TABLE_BYTES + (size_t)p.PH * p.PW * p.pixstride + (p.wlds ? (size_t)p.nsteps * p.NF * 1024 : 0);
     lds = (lds + 15) & ~(size_t)15;

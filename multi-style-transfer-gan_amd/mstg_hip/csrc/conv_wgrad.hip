@@ -954,30 +954,43 @@ static size_t wgrad_1x1_workspace(const WGradArgs& a) {
 }
 
 // dw[gch*s_g + hch*s_h + t] = sum_split partial[split][t][gch][hch]  (+ dbias[hch] from the tail of each split's block).
-// A workgroup owns 16 consecutive outputs; its 16 thread-rows stride over the splits and are combined through LDS in a
-// fixed order, so the result does not depend on scheduling.
+// A workgroup owns 64 consecutive outputs: thread (row = tid >> 4, q = tid & 15) sums outputs 4q .. 4q+3 of every 16th split with
+// one 16-byte load per split (a row's 16 threads read 256 contiguous bytes; the round-2 kernel read 64), the 16 rows are combined
+// through LDS in a fixed order: per output the summation order is split row, row + 16, ... then rows 0..15 -- the order the
+// narrower kernel used, so results are bit-identical to it and independent of scheduling.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                            float* __restrict__ dbias, int S, int T, int Cg, int Ch, int s_g,
                                                            int s_h, int pstride, int accumulate) {
-    __shared__ float sh[16][17];
-    const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
+    __shared__ f32x4 sh[16][17];
+    const int q = threadIdx.x & 15, row = threadIdx.x >> 4;
     const int total = T * Cg * Ch, nout = pstride;
-    const int idx = blockIdx.x * 16 + e;
-    float sum = 0.f;
-    if (idx < nout)
-        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * pstride + idx];
-    sh[row][e] = sum;
+    const int idx = (blockIdx.x * 16 + q) * 4;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if ((pstride & 3) == 0) {
+        if (idx < nout)
+            for (int sp = row; sp < S; sp += 16) sum += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * pstride + idx);
+    } else {
+        for (int sp = row; sp < S; sp += 16)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (idx + c < nout) sum[c] += partial[(size_t)sp * pstride + idx + c];
+    }
+    sh[row][q] = sum;
     __syncthreads();
     if (row == 0 && idx < nout) {
-        float r = 0.f;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r += sh[k][e];
-        if (idx < total) {
-            const int hch = idx % Ch, gch = (idx / Ch) % Cg, t = idx / (Ch * Cg);
-            float* o = dw + (size_t)gch * s_g + (size_t)hch * s_h + t;
-            *o = accumulate ? *o + r : r;
-        } else if (dbias) {
-            dbias[idx - total] = accumulate ? dbias[idx - total] + r : r;
+        for (int k = 0; k < 16; ++k) r += sh[k][q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int id = idx + c;
+            if (id < total) {
+                const int hch = id % Ch, gch = (id / Ch) % Cg, t = id / (Ch * Cg);
+                float* o = dw + (size_t)gch * s_g + (size_t)hch * s_h + t;
+                *o = accumulate ? *o + r[c] : r[c];
+            } else if (id < nout && dbias) {
+                dbias[id - total] = accumulate ? dbias[id - total] + r[c] : r[c];
+            }
         }
     }
 }
@@ -1299,7 +1312,7 @@ static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const floa
                 if (rc) return rc;
                 // the partial slabs are reused by the next block: stream order keeps this reduce ahead of the next launch
                 const int pstride = b.Cg * b.Ch + (b.with_bias ? b.Ch : 0);
-                MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial,
+                MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 64)), dim3(256), 0, st, a.partial,
                                    dw + (size_t)(ig * c.wg) * s_g + (size_t)(ih * c.wh) * s_h, b.with_bias ? dbias + ih * c.wh : nullptr, Sb, 1,
                                    b.Cg, b.Ch, s_g, s_h, pstride, d->accumulate);
                 MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
@@ -1344,7 +1357,7 @@ static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const floa
     const int s_g = T;
     const int s_h = d->transposed ? d->Cout * T : d->Cin * T;
     const int pstride = total + (a.with_bias ? a.Ch : 0);
-    MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 16)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
+    MSTG_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(pstride, 64)), dim3(256), 0, st, a.partial, dw, dbias, S, T, a.Cg, a.Ch, s_g, s_h,
                        pstride, d->accumulate);
     MSTG_CHECK_LAUNCH("wgrad_reduce_kernel");
     return MSTG_OK;

@@ -113,6 +113,30 @@ __global__ void tensor_to_u8_kernel(const float* __restrict__ y, int H, int W, u
     }
 }
 
+// result = clip(orig * (1 - w) + styled * w, 0, 255).astype(uint8) as numpy evaluates it on uint8 arrays and a float64 weight
+// (batch_process_images.py:308-310 with a scalar strength, :340-342 + :352 with a per-pixel weight map): two float64 products,
+// each rounded, one rounded sum (no fused multiply-add -- numpy has none here), clip, truncation.  w0 = 1 - strength is formed on
+// the host in the scalar case (Python's own double subtraction), per pixel in float64 with a map.  Byte arithmetic: HBM-bound.
+__global__ void blend_u8_kernel(const unsigned char* __restrict__ orig, const unsigned char* __restrict__ styled, double w0, double w1,
+                                const double* __restrict__ wmap, unsigned char* __restrict__ out, size_t npix) {
+#pragma clang fp contract(off)  // numpy rounds each product and the sum; hipcc would fuse them (it does so even through __dmul_rn / __dadd_rn)
+    const size_t px = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= npix) return;
+    if (wmap) {
+        w1 = wmap[px];
+        w0 = 1.0 - w1;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const double a = (double)orig[px * 3 + c] * w0;
+        const double b = (double)styled[px * 3 + c] * w1;
+        double r = a + b;
+        r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
+        if (!(r == r)) r = 0.0;  // a NaN weight: numpy's cast is undefined there; keep the byte defined
+        out[px * 3 + c] = (unsigned char)r;
+    }
+}
+
 // ---- Pillow's coefficient tables (host, double precision) ---------------------------------------------------------------------
 static double bilinear_filter(double x) {
     if (x < 0.0) x = -x;
@@ -225,5 +249,15 @@ extern "C" int mstg_tensor_to_u8(const float* y, int H, int W, unsigned char* ds
     if (H > 65535) return fail_arg(MSTG_E_UNSUPPORTED, "tensor_to_u8: more than 65535 rows");
     MSTG_LAUNCH(tensor_to_u8_kernel, dim3(cdiv(W, 128), H), dim3(128), 0, (hipStream_t)stream, y, H, W, dst);
     MSTG_CHECK_LAUNCH("tensor_to_u8_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_blend_u8(const unsigned char* orig, const unsigned char* styled, double one_minus_strength, double strength,
+                             const double* weight_map, unsigned char* out, int H, int W, void* stream) {
+    if (!orig || !styled || !out || H <= 0 || W <= 0) return fail_arg(MSTG_E_BADARG, "blend_u8: bad argument");
+    const size_t npix = (size_t)H * W;
+    MSTG_LAUNCH(blend_u8_kernel, dim3((unsigned)cdivz(npix, 256)), dim3(256), 0, (hipStream_t)stream, orig, styled, one_minus_strength,
+                strength, weight_map, out, npix);
+    MSTG_CHECK_LAUNCH("blend_u8_kernel");
     return MSTG_OK;
 }

@@ -715,7 +715,7 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
     const size_t need = (size_t)(NCH * G::U * 256 + CH) * sizeof(float);
     if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_fwd: workspace too small");
     float* wp = (float*)ws;
-    MSTG_LAUNCH((ms_pack_fwd_kernel<CH>), dim3(cdiv(NCH * G::U * 256 + CH, 256)), dim3(256), 0, st, prm, wp);
+    MSTG_PACK_LAUNCH((ms_pack_fwd_kernel<CH>), dim3(cdiv(NCH * G::U * 256 + CH, 256)), dim3(256), 0, st, prm, wp);
     MSTG_CHECK_LAUNCH("ms_pack_fwd_kernel");
     const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
     const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
@@ -736,7 +736,7 @@ static int launch_ms_dgrad(const float* dy, const MsParamPtrs& prm, const float*
     const size_t need = ms_dgrad_ws_floats<CH>() * sizeof(float);
     if (!ws || ws_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "msblock_dgrad: workspace too small");
     float* wp = (float*)ws;
-    MSTG_LAUNCH((ms_pack_dgrad_kernel<CH>), dim3(cdiv((int)ms_dgrad_ws_floats<CH>(), 1024)), dim3(256), 0, st, prm, wp);
+    MSTG_PACK_LAUNCH((ms_pack_dgrad_kernel<CH>), dim3(cdiv((int)ms_dgrad_ws_floats<CH>(), 1024)), dim3(256), 0, st, prm, wp);
     MSTG_CHECK_LAUNCH("ms_pack_dgrad_kernel");
     const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, MS_TH);
     const size_t lds = (size_t)(MS_PH * MS_PW * MS_CKP) * sizeof(float);
@@ -789,6 +789,24 @@ extern "C" int mstg_msblock_fwd(const float* x, const float* w1, const float* b1
     if (CH == 32) return launch_ms_fwd<32>(x, prm, y, N, H, W, workspace, workspace_bytes, st);
     if (CH == 64) return launch_ms_fwd<64>(x, prm, y, N, H, W, workspace, workspace_bytes, st);
     return fail_arg(MSTG_E_UNSUPPORTED, "msblock_fwd: fused path exists for 16, 32 and 64 channels");
+}
+
+// the same two entry points for a caller that caches the packed filters (common.h: t_ws_packed)
+extern "C" int mstg_msblock_fwd_cached(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* w3,
+                                       const float* b3, const float* w4, const float* b4, float* y, int N, int H, int W, int CH,
+                                       void* workspace, size_t workspace_bytes, int workspace_packed, void* stream) {
+    mstg::t_ws_packed = workspace_packed != 0;
+    const int rc = mstg_msblock_fwd(x, w1, b1, w2, b2, w3, b3, w4, b4, y, N, H, W, CH, workspace, workspace_bytes, stream);
+    mstg::t_ws_packed = false;
+    return rc;
+}
+extern "C" int mstg_msblock_dgrad_cached(const float* dy, const float* w1, const float* w2, const float* w3, const float* w4,
+                                         const float* dres, float* dx, int N, int H, int W, int CH, void* workspace, size_t workspace_bytes,
+                                         int workspace_packed, void* stream) {
+    mstg::t_ws_packed = workspace_packed != 0;
+    const int rc = mstg_msblock_dgrad(dy, w1, w2, w3, w4, dres, dx, N, H, W, CH, workspace, workspace_bytes, stream);
+    mstg::t_ws_packed = false;
+    return rc;
 }
 
 extern "C" size_t mstg_msblock_wgrad_workspace_bytes(int N, int H, int W, int CH) {

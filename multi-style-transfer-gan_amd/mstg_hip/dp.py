@@ -53,6 +53,8 @@ def allreduce_mean_(flat: torch.Tensor) -> torch.Tensor:
 def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
     if world_size() > 1:
         dist.broadcast(flat, src=src)
+        from . import ops
+        ops.bump_pack_epoch()  # the collective wrote parameter memory without touching torch's version counters
     return flat
 
 

@@ -122,7 +122,31 @@ def to_u8(y: torch.Tensor) -> torch.Tensor:
     return out
 
 
-# ---- the two callers, restated on the device ----------------------------------------------------------------------------------
+def blend_u8(orig: torch.Tensor, styled: torch.Tensor, strength=None, weight_map=None) -> torch.Tensor:
+    """``np.clip(orig * (1 - w) + styled * w, 0, 255).astype(np.uint8)`` on two (H, W, 3) uint8 images, bit for bit as numpy
+    evaluates it in float64: w = the scalar ``strength`` (process_local_style mode 'simple', batch_process_images.py:304-312) or a
+    float64 (H, W) ``weight_map`` (the 'enhanced' / 'advanced' blend of :340-342, :386-387 given a mask made on the host)."""
+    orig, styled = _req_u8(orig), _req_u8(styled)
+    if orig.shape != styled.shape:
+        raise RuntimeError(f"mstg_hip blend: shapes differ {tuple(orig.shape)} vs {tuple(styled.shape)}")
+    if (strength is None) == (weight_map is None):
+        raise RuntimeError("mstg_hip blend: give either strength or weight_map")
+    H, W = orig.shape[:2]
+    out = torch.empty_like(orig)
+    if weight_map is not None:
+        wm = torch.as_tensor(weight_map)
+        if tuple(wm.shape) != (H, W):
+            raise RuntimeError(f"mstg_hip blend: weight map {tuple(wm.shape)} does not match the image {H}x{W}")
+        wm = wm.to(device=orig.device, dtype=torch.float64).contiguous()
+        w0 = w1 = 0.0
+    else:
+        wm, w1 = None, float(strength)
+        w0 = 1 - w1  # Python's double subtraction, as in the reference's expression
+    _lib.check(_lib.load().mstg_blend_u8(_p(orig), _p(styled), w0, w1, _p(wm), _p(out), H, W, _stream()), "mstg_blend_u8")
+    return out
+
+
+# ---- the callers, restated on the device ----------------------------------------------------------------------------------
 def dataset_item(img_u8: torch.Tensor, grid_mask: int, img_size: int = 256):
     """MonetPhotoDataset.__getitem__ (pretrain.py:41-57) from a decoded uint8 image on the GPU: Resize(img_size) (shorter side,
     bilinear) -> CenterCrop -> ToTensor -> Normalize -> 8x8-grid mask.  Returns (masked_image, image, mask)."""
@@ -163,6 +187,38 @@ def process_cyclegan(model, img_u8: torch.Tensor, target=256) -> torch.Tensor:
             crop_w, crop_h = target, int(target / aspect)
         else:
             crop_h, crop_w = target, int(target * aspect)
+        left, top = (target - crop_w) // 2, (target - crop_h) // 2
+        out = crop_u8(out, left, top, left + crop_w, top + crop_h)
+    if width * height <= 1024 * 1024:
+        out = resize_u8(out, (width, height), LANCZOS)
+    return out
+
+
+def process_local_style(model, img_u8: torch.Tensor, mode="simple", strength=0.8, weight_map=None, target=256) -> torch.Tensor:
+    """``process_local_style`` of the reference (batch_process_images.py:255-441) without the file I/O, on the GPU end to end for
+    the modes that are byte arithmetic: 'simple' (strength blend of the letterboxed original with the styled image, :304-312),
+    'weight_map' (the per-pixel blend of the 'enhanced' mode, :340-342 + :352, with the (target, target) float64 weight map the
+    caller built -- cv2.Canny / scipy.gaussian_filter / the sky detector are host code outside this library), and any other mode
+    name = the reference's default branch (the styled image itself, :399-401).  Crop back to the aspect ratio and LANCZOS resize
+    back as :403-429."""
+    canvas, (width, height) = letterbox(img_u8, target)
+    x = to_tensor(canvas).unsqueeze(0)
+    with torch.no_grad():
+        y = model(x)
+    styled = to_u8(y[0])
+    if mode == "simple":
+        out = blend_u8(canvas, styled, strength=strength)
+    elif mode == "weight_map":
+        out = blend_u8(canvas, styled, weight_map=weight_map)
+    else:
+        out = styled
+    aspect = width / height
+    if aspect != 1.0:
+        if aspect > 1:
+            crop_w, crop_h = target, int(target / aspect)
+        else:
+            crop_h, crop_w = target, int(target * aspect)
+        crop_w, crop_h = min(crop_w, target), min(crop_h, target)
         left, top = (target - crop_w) // 2, (target - crop_h) // 2
         out = crop_u8(out, left, top, left + crop_w, top + crop_h)
     if width * height <= 1024 * 1024:

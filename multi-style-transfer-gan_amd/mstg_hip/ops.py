@@ -202,21 +202,72 @@ def _kernel_name(d: ConvDesc, which: int) -> str:
     return _lib.load().mstg_conv2d_kernel_name(C.byref(d), which).decode() if KernelTimer.enabled else ""
 
 
-def conv_fwd_raw(d: ConvDesc, x, w, b, y):
+# ----------------------------------------------------------------------------------------------------------
+# Filter packs kept between launches
+# ----------------------------------------------------------------------------------------------------------
+# Every convolution launch of the library starts by re-packing its filter into the workspace (a ~5 us kernel; ~170 of them per
+# CycleGAN step, where each generator runs three forwards and three backwards on unchanged weights).  When the layer OWNS its
+# filter (the tensors are nn.Parameters) the workspace is kept on the parameter object and the *_cached entry points skip the pack
+# while the stamp below is unchanged.  What can change a parameter's values, and how the stamp sees it:
+#   * torch in-place ops on the parameter (load_state_dict, p.copy_, ...)         -> p._version
+#   * torch in-place ops on the optimizer's flat buffer it is a view of             -> flat._version (FlatAdam sets p._mstg_flat)
+#   * raw-pointer writers: the fused Adam step, the DP broadcast of the flat buffer -> PACK_EPOCH, bumped by those call sites
+#   * p.data re-homed (module.to / .half / a new FlatAdam)                          -> data_ptr
+# The cache dies with the parameter object (no address-reuse hazard), is per stream (the two halves of the train step never share
+# a workspace) and is never used for tensors that are not Parameters (the discriminator's W / sigma temporaries).
+# MSTG_NO_PACK_CACHE=1 switches it off.
+PACK_EPOCH = [0]
+
+
+def bump_pack_epoch() -> None:
+    """Call after writing parameter memory behind torch's back (a kernel handed raw pointers)."""
+    PACK_EPOCH[0] += 1
+
+
+def _pack_stamp(owners):
+    return tuple(None if t is None else (id(t), t.data_ptr(), t._version, getattr(getattr(t, "_mstg_flat", None), "_version", -1))
+                 for t in owners) + (PACK_EPOCH[0],)
+
+
+def _cached_ws(owners, kind, dkey, nbytes: int, device):
+    """(workspace, 1 if it still holds this call's filter pack else 0)"""
+    if (not owners or owners[0] is None or os.environ.get("MSTG_NO_PACK_CACHE", "0") == "1"
+            or not all(t is None or isinstance(t, torch.nn.Parameter) for t in owners)):
+        return _ws(nbytes, device), 0
+    packs = owners[0].__dict__.setdefault("_mstg_packs", {})
+    key = (kind, dkey, torch.cuda.current_stream().cuda_stream)
+    stamp = _pack_stamp(owners)
+    ent = packs.get(key)
+    if ent is not None and ent[0].numel() * 4 >= nbytes:
+        if ent[1] == stamp:
+            return ent[0], 1
+        packs[key] = (ent[0], stamp)  # same stream: the re-pack is ordered behind every launch that still reads the old one
+        return ent[0], 0
+    ws = _ws(nbytes, device)
+    packs[key] = (ws, stamp)
+    return ws, 0
+
+
+def _dkey(d: ConvDesc):
+    return tuple(getattr(d, n) for n, _ in ConvDesc._fields_)
+
+
+def conv_fwd_raw(d: ConvDesc, x, w, b, y, owners=None):
+    """owners: the (weight, bias) objects of the calling layer when it owns them (nn.Parameters) -> their pack is kept."""
     fl, by = _conv_cost(d)
     lib = _lib.load()
-    ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
+    ws, packed = _cached_ws(owners, "fwd", _dkey(d), lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
     _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
-        lib.mstg_conv2d_fwd(C.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_fwd"),
+        lib.mstg_conv2d_fwd_cached(C.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel() * 4, packed, _stream()), "mstg_conv2d_fwd"),
         _conv_detail("fwd", d))
 
 
-def conv_dgrad_raw(d: ConvDesc, dy, w, dx):
+def conv_dgrad_raw(d: ConvDesc, dy, w, dx, owners=None):
     fl, by = _conv_cost(d)
     lib = _lib.load()
-    ws = _ws(lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
+    ws, packed = _cached_ws(owners, "dgrad", _dkey(d), lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
     _timed(_kernel_name(d, 1), fl, by, lambda: _lib.check(
-        lib.mstg_conv2d_dgrad(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel() * 4, _stream()), "mstg_conv2d_dgrad"),
+        lib.mstg_conv2d_dgrad_cached(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel() * 4, packed, _stream()), "mstg_conv2d_dgrad"),
         _conv_detail("dgrad", d))
 
 
@@ -275,7 +326,7 @@ class ConvFn(torch.autograd.Function):
             raise RuntimeError(f"mstg_hip conv: input {H}x{W} too small for kernel {k} (stride {stride}, pad {pad}, dil {dil})")
         y = torch.empty((N, Cout, Ho, Wo) if y_nchw else (N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
-        conv_fwd_raw(d, x, w, b, y)
+        conv_fwd_raw(d, x, w, b, y, owners=(w, b))
         ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
         # the objects handed to apply() are nn.Parameters when the layer owns them; only their .grad slots are looked up through
         # these references in backward (see _grad_slot) -- the VALUES used there come from saved_tensors (version-checked)
@@ -295,7 +346,7 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            conv_dgrad_raw(d, dy, w, dx)
+            conv_dgrad_raw(d, dy, w, dx, owners=(ctx.prefs[0],))
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
@@ -345,11 +396,11 @@ class ConvStatsFn(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         stats = torch.empty((N, Cout, 2), dtype=torch.float32, device=x.device)
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
-        ws = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
+        ws, packed = _cached_ws((w, b), "fwd_norm", _dkey(d), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
         fl, by = _conv_cost(d)
         _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(  # the STATS instantiation
-            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(x), None, _p(w), _p(b), _p(y), _p(stats), _p(ws), ws.numel() * 4, _stream()),
-            "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
+            lib.mstg_conv2d_fwd_norm_cached(C.byref(d), _p(x), None, _p(w), _p(b), _p(y), _p(stats), _p(ws), ws.numel() * 4, packed,
+                                            _stream()), "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
         ctx.cfg, ctx.dims, ctx.has_bias = (k, stride, pad, dil, transposed, 0, 0, ACT_NONE), (N, H, W, Cin, Ho, Wo, Cout), b is not None
         ctx.prefs = (w, b)
         ctx.save_for_backward(x, w, None)
@@ -389,11 +440,11 @@ class MSFusionFn(torch.autograd.Function):
         y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
         ystats = torch.empty((N, Cout, 2), dtype=torch.float32, device=cat.device)  # (mean, rstd) of y from the epilogue
         d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
-        ws2 = _ws(lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
+        ws2, packed = _cached_ws((w, b), "fwd_norm", _dkey(d), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
         fl, by = _conv_cost(d)
         _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(
-            lib.mstg_conv2d_fwd_norm(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), _p(ystats), _p(ws2), ws2.numel() * 4, _stream()),
-            "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
+            lib.mstg_conv2d_fwd_norm_cached(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), _p(ystats), _p(ws2), ws2.numel() * 4,
+                                            packed, _stream()), "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
         ctx.dims, ctx.has_bias, ctx.prefs = (N, H, W, Cn, Cout), b is not None, (w, b)
         ctx.save_for_backward(cat, stats, w)
         ctx.mark_non_differentiable(ystats)
@@ -409,7 +460,7 @@ class MSFusionFn(torch.autograd.Function):
         dcat = dw = db = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(cat)
-            conv_dgrad_raw(d, dy, w, dz)  # gradient w.r.t. the normalised concat
+            conv_dgrad_raw(d, dy, w, dz, owners=(ctx.prefs[0],))  # gradient w.r.t. the normalised concat
             dcat = torch.empty_like(cat)
             ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
             _timed("norm_apply_kernel<true>", 0, 4 * cat.numel() * 3, lambda: _lib.check(
@@ -459,14 +510,14 @@ class MSBranchesFn(torch.autograd.Function):
         y = torch.empty((N, H, W, 4 * c4), dtype=torch.float32, device=x.device)
         lib = _lib.load()
         if os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch:
-            wsb = _ws(lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
+            wsb, packed = _cached_ws(tuple(wb), "ms_fwd", (N, H, W, ch), lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
             wb_ptrs = []
             for j in range(4):
                 wb_ptrs += [_p(ws[j]), _p(bs[j])]
             fwd4 = ch == 16 and H >= 16 and os.environ.get("MSTG_MS_FWD4", "1") != "0"
             _timed("ms_fwd4_kernel" if fwd4 else f"ms_fwd_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
-                   lambda: _lib.check(lib.mstg_msblock_fwd(_p(x), *wb_ptrs, _p(y), N, H, W, ch, _p(wsb), wsb.numel() * 4, _stream()),
-                                      "mstg_msblock_fwd"), f"ms-fwd N{N} {H}x{W} ch{ch}")
+                   lambda: _lib.check(lib.mstg_msblock_fwd_cached(_p(x), *wb_ptrs, _p(y), N, H, W, ch, _p(wsb), wsb.numel() * 4, packed,
+                                                                  _stream()), "mstg_msblock_fwd"), f"ms-fwd N{N} {H}x{W} ch{ch}")
         else:
             for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
                 d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4)
@@ -490,10 +541,10 @@ class MSBranchesFn(torch.autograd.Function):
         fused = os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch
         grads = []
         if fused and dx is not None:  # dx of all four branches in one pass over dy, written once
-            wsd = _ws(lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
+            wsd, packed = _cached_ws(tuple(ctx.prefs[0::2]), "ms_dgrad", (N, H, W, ch), lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
             _timed(f"ms_dgrad_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
-                   lambda: _lib.check(lib.mstg_msblock_dgrad(_p(dy), *[_p(t) for t in ws], _p(dres), _p(dx), N, H, W, ch, _p(wsd),
-                                                             wsd.numel() * 4, _stream()), "mstg_msblock_dgrad"),
+                   lambda: _lib.check(lib.mstg_msblock_dgrad_cached(_p(dy), *[_p(t) for t in ws], _p(dres), _p(dx), N, H, W, ch, _p(wsd),
+                                                                    wsd.numel() * 4, packed, _stream()), "mstg_msblock_dgrad"),
                    f"ms-dgrad N{N} {H}x{W} ch{ch}")
         for j, (k, pad, dil) in enumerate(MSBranchesFn.GEOM):
             d = make_desc(N, H, W, ch, H, W, c4, k, 1, pad, dil, y_ctot=4 * c4, y_coff=j * c4, accumulate=int(j > 0))
@@ -1147,5 +1198,6 @@ def linear_tokens(x, weight, bias, act=ACT_NONE):
 
 
 def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, step, mask=None):
+    bump_pack_epoch()  # parameter memory is about to change behind torch's version counters
     _lib.check(_lib.load().mstg_adam_step_flat(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step), _p(mask),
                                                _stream()), "mstg_adam_step_flat")

@@ -40,6 +40,7 @@ class FlatAdam:
                 view = self.flat[o:o + p.numel()].view_as(p)
                 view.copy_(p.data)
                 p.data = view
+                p._mstg_flat = self.flat  # ops' filter-pack cache watches this buffer's version counter too
         self._attach_grads()
 
     def _attach_grads(self):

@@ -171,3 +171,51 @@ def process_cyclegan_ref(model_fn, img: np.ndarray, target: int = 256, resize=pi
     if width * height <= 1024 * 1024:
         out = resize(np.ascontiguousarray(out), (width, height), LANCZOS)
     return out
+
+
+def blend_simple(orig: np.ndarray, styled: np.ndarray, strength: float) -> np.ndarray:
+    """batch_process_images.py:306-310 (mode 'simple'): the reference's own numpy expression on two uint8 HWC arrays"""
+    result = orig * (1 - strength) + styled * strength
+    return np.clip(result, 0, 255).astype(np.uint8)
+
+
+def blend_weight_map(orig: np.ndarray, styled: np.ndarray, weight: np.ndarray) -> np.ndarray:
+    """batch_process_images.py:340-342 + :352 (mode 'enhanced' with enhance_colors / smooth off; :386-387 is the same expression):
+    weight (H, W) float64 -> per-pixel blend, clip, uint8"""
+    weight = np.asarray(weight, dtype=float)[:, :, np.newaxis]
+    result = orig * (1 - weight) + styled * weight
+    return np.clip(result, 0, 255).astype(np.uint8)
+
+
+def process_local_style_ref(model_fn, img: np.ndarray, mode="simple", strength=0.8, weight_map=None, target: int = 256,
+                            resize=pil_resize) -> np.ndarray:
+    """process_local_style (batch_process_images.py:255-441) without file I/O for mode 'simple', 'weight_map' (the 'enhanced'
+    blend given its weight map) and the default branch; ``model_fn``: (1,3,T,T) float32 -> (1,3,T,T) float32"""
+    height, width = img.shape[:2]
+    if width > height:
+        new_width, new_height = target, int(height * (target / width))
+    else:
+        new_height, new_width = target, int(width * (target / height))
+    resized = resize(img, (new_width, new_height), LANCZOS)
+    canvas = np.full((target, target, 3), 255, dtype=np.uint8)
+    off_x, off_y = (target - new_width) // 2, (target - new_height) // 2
+    canvas[off_y:off_y + new_height, off_x:off_x + new_width] = resized
+    styled = output_to_u8(np.asarray(model_fn(to_tensor_normalize(canvas)[None]))[0])
+    if mode == "simple":
+        out = blend_simple(canvas, styled, strength)
+    elif mode == "weight_map":
+        out = blend_weight_map(canvas, styled, weight_map)
+    else:
+        out = styled
+    aspect = width / height
+    if aspect != 1.0:
+        if aspect > 1:
+            crop_w, crop_h = target, int(target / aspect)
+        else:
+            crop_h, crop_w = target, int(target * aspect)
+        crop_w, crop_h = min(crop_w, target), min(crop_h, target)
+        left, top = (target - crop_w) // 2, (target - crop_h) // 2
+        out = out[top:top + crop_h, left:left + crop_w]
+    if width * height <= 1024 * 1024:
+        out = resize(np.ascontiguousarray(out), (width, height), LANCZOS)
+    return out

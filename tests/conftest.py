@@ -16,6 +16,30 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def usable_cpus() -> int:
+    """Cores this process may really use (the GPU box shows 256 logical CPUs and grants 16 through its cgroup): torch sizes its
+    thread pool by the former, and an oracle run then crawls under 16x oversubscription."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads():
+    import torch
+    torch.set_num_threads(max(1, min(usable_cpus(), 16)))
+    yield
+
+
 @pytest.fixture(scope="session")
 def gold_dir():
     return GOLD

@@ -96,6 +96,65 @@ def test_process_cyclegan_matches_reference_composition(shape):
     assert np.array_equal(out, ref), f"{int((out != ref).sum())} of {out.size} bytes differ"
 
 
+@pytest.mark.parametrize("strength", [0.8, 0.0, 1.0, 0.3, 0.55, 1.0 / 3.0, 1.2])
+def test_blend_simple_bit_exact(strength):
+    """mode 'simple' of process_local_style (batch_process_images.py:304-312): byte arithmetic, bit-exact against the numpy
+    restatement (every (orig, styled) byte pair occurs: 256 x 256 pixels per channel)."""
+    from mstg_hip import image as dimg
+    a = np.repeat(np.arange(256, dtype=np.uint8)[:, None, None], 256, axis=1).repeat(3, axis=2)
+    b = np.ascontiguousarray(a.transpose(1, 0, 2))
+    b[..., 1] = b[::-1, :, 1]
+    out = dimg.blend_u8(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), strength=strength).cpu().numpy()
+    ref = IR.blend_simple(a, b, strength)
+    assert np.array_equal(out, ref), f"{int((out != ref).sum())} bytes differ at strength {strength}"
+
+
+def test_blend_weight_map_bit_exact():
+    """The per-pixel blend of the 'enhanced' mode (batch_process_images.py:340-342, :352) with a weight map made the way the
+    reference makes it (strength everywhere, stronger in one region, detail_weight in another), plus random float64 weights."""
+    from mstg_hip import image as dimg
+    rs = np.random.RandomState(5)
+    a, b = _img(200, 312, 21), _img(200, 312, 22)
+    strength, detail = 0.8, 0.7
+    weight = np.ones((200, 312), dtype=float) * strength
+    weight[:60] = min(strength + 0.2, 1.0)
+    weight[rs.rand(200, 312) > 0.7] = max(strength - 0.3 * detail, 0.0)
+    for wm in (weight, rs.rand(200, 312), np.zeros((200, 312)), np.ones((200, 312))):
+        out = dimg.blend_u8(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), weight_map=torch.from_numpy(wm)).cpu().numpy()
+        ref = IR.blend_weight_map(a, b, wm)
+        assert np.array_equal(out, ref), f"{int((out != ref).sum())} bytes differ"
+    with pytest.raises(RuntimeError):
+        dimg.blend_u8(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV))
+    with pytest.raises(RuntimeError):
+        dimg.blend_u8(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), weight_map=torch.zeros(3, 3))
+
+
+@pytest.mark.parametrize("shape,mode", [((300, 420), "simple"), ((420, 300), "weight_map"), ((256, 256), "simple"), ((200, 333), "styled")])
+def test_process_local_style_matches_reference_composition(shape, mode):
+    """process_local_style (batch_process_images.py:255-441) on the device for the byte-arithmetic modes, real generator in the
+    middle, against the PIL / numpy composition given the same forward."""
+    import warnings
+
+    import enhanced_generator as eg
+    from mstg_hip import image as dimg
+    from oracle import restatement as R
+    m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
+    m.load_state_dict(R.make_state_dict(R.generator_spec_with_blocks(16, 1), 78))
+    m.to(DEV).eval()
+    img = _img(shape[0], shape[1], 12)
+    wm = np.random.RandomState(3).rand(256, 256) if mode == "weight_map" else None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out = dimg.process_local_style(m, torch.from_numpy(img).to(DEV), mode=mode, strength=0.65, weight_map=wm).cpu().numpy()
+
+        def model_fn(x):
+            with torch.no_grad():
+                return m(torch.from_numpy(np.ascontiguousarray(x)).to(DEV)).cpu().numpy()
+        ref = IR.process_local_style_ref(model_fn, img, mode=mode, strength=0.65, weight_map=wm, resize=_pil_or_numpy())
+    assert out.shape == ref.shape == (shape[0], shape[1], 3)
+    assert np.array_equal(out, ref), f"{int((out != ref).sum())} of {out.size} bytes differ"
+
+
 def test_masked_l1_and_clip_grad_norm_vs_torch():
     from mstg_hip import ops
     g = torch.Generator().manual_seed(2)

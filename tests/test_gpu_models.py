@@ -295,15 +295,17 @@ def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
     What a correct fp32 implementation can reach here is a distribution, not a number: two chained generators flip ReLU masks,
     and the reference's OWN fp32 evaluation of a forced step sits 2e-4 (10th percentile) ... 5e-3 (median) ... 2e-2 (90th) from
     its fp64 evaluation over 80 draws x 3 steps of this shape (stored in the fixture, oracle/make_golden.py).  The fixture's draw
-    was chosen because the reference is lucky on it (< 1e-3 at all three steps), which makes step 0 and the optimizer plumbing a
-    sharp pin, but another fp32 implementation need not share that luck.  Bars:
-      losses            max(1e-3, 1.5 x the reference's own fp32 distance on this draw)
-      gradients, all    max(1e-3, 1.5 x the reference's own fp32 distance on this draw, MEDIAN of the reference's distribution)
-      gradients, each   max(1e-3, 1.5 x that tensor's / 1.5 x the worst tensor's reference distance on this draw, 5 x the bar above --
-                        the spread between aggregate and worst tensor the reference itself shows)
-    and the test prints where the build's aggregate falls in the reference's distribution.  Also checked per step: Adam's first moment after the step against
-    b1*m + (1-b1)*g64 (relative), and the parameter update against the fp64 update on every element whose fp64 gradient is not
-    rounding noise."""
+    was chosen because the reference is lucky on it (< 1e-3 at all three steps).  Bars:
+      losses, every step            max(1e-3, 1.5 x the reference's own fp32 distance on this draw)
+      gradients at step 0           aggregate max(1e-3, 1.5 x the reference's own fp32 distance on this draw); each tensor
+                                    max(1e-3, 1.5 x that tensor's / the worst live tensor's reference distance on this draw)
+      gradients at steps 1, 2       one draw cannot tell flip noise from a systematic error (the build need not share the
+                                    reference's luck on this draw): the aggregate only has to lie inside the reference's own
+                                    distribution (95th percentile of the scan); the sharp statement about these steps is
+                                    test_train_step_gradient_distance_distribution below (32 fresh draws x 3 forced steps)
+    and the test prints where the build's aggregate falls in the reference's distribution.  Also checked per step: Adam's first
+    moment after the step is b1*m + (1-b1)*g for the gradient the optimizer actually saw (exactly linear: 1e-5), and the
+    parameter update against the fp64 update on every element whose fp64 gradient is not rounding noise."""
     from fp64_fixture import BETAS, LOSS_KEYS, Fp64TrainStepFixture, dead_bias
     from oracle import restatement as R
     fx = Fp64TrainStepFixture(gold_dir)
@@ -356,7 +358,8 @@ def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
             # flips upstream): a tensor may be as far out as 1.5x the reference's own worst live tensor of this step
             ref_worst = max(d for n_, d in zip(fx.names[which], dist32) if d >= 0 and not dead_bias(n_))
             scan = fx.scan(which)
-            agg_bound = max(1e-3, 1.5 * agg32, float(np.median(scan)) if which == "g" else 0.0)
+            strict = k == 0 or which == "d"
+            agg_bound = max(1e-3, 1.5 * agg32) if strict else max(1e-3, 1.5 * agg32, float(np.percentile(scan, 95)))
             num = den = 0.0
             rows = []
             p_before, m_before, _ = expect[which]
@@ -371,13 +374,13 @@ def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
                 if dead_bias(n):
                     continue
                 e = float((mine - r).norm() / r.norm().clamp_min(1e-300))
-                bound = max(1e-3, 1.5 * dist32[i], 1.5 * ref_worst, 5.0 * agg_bound if which == "g" else 0.0)
+                bound = max(1e-3, 1.5 * dist32[i], 1.5 * ref_worst) if strict else float("inf")
                 worst = max(worst, e / bound)
                 rows.append((e / bound, n, e, dist32[i], bound))
                 num += float((mine - r).pow(2).sum())
                 den += float(r.pow(2).sum())
-                # Adam's first moment after the step: linear in the gradient
-                m_exp = BETAS[0] * m_before[i].reshape(-1) + (1 - BETAS[0]) * r
+                # Adam's first moment after the step: linear in the gradient the optimizer saw
+                m_exp = BETAS[0] * m_before[i].reshape(-1) + (1 - BETAS[0]) * mine
                 m_num += float((m_flat[off:off + prm.numel()] - m_exp).pow(2).sum())
                 m_den += float(m_exp.pow(2).sum())
                 # parameter update (checked below) on elements whose gradient is not rounding noise (|g| > 1e-2 rms)
@@ -392,7 +395,7 @@ def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
             for ratio, n, e, d32, bound in rows:
                 assert e <= bound, (k, which, n, e, bound, d32)
             assert agg <= agg_bound, (k, which, agg, agg_bound)
-            assert (m_num / max(m_den, 1e-300)) ** 0.5 <= agg_bound, (k, which, "exp_avg")
+            assert (m_num / max(m_den, 1e-300)) ** 0.5 <= 1e-5, (k, which, "exp_avg")
         # update direction / size: the state after this step vs the fp64 state at the start of the next one
         for which, opt in opts.items():
             p_next, _, _ = fx.state_at(which, k + 1, p0[which])
@@ -409,6 +412,141 @@ def test_train_step_teacher_forced_vs_reference_fp64(gold_dir):
             assert rel_upd <= 5e-2, (k, which, rel_upd)
             expect.pop(("live", which))
     print(f"  [parity] fp64-forced: worst tensor at {worst:.2f} of its bound")
+
+
+def test_train_step_gradient_distance_distribution():
+    """Is the HIP train step's backward as close to exact arithmetic as a correct fp32 implementation can be?  One draw cannot
+    answer that (ReLU / |.| masks flip under ANY change of fp32 summation order, and how many flip depends on the draw), so this
+    test compares DISTRIBUTIONS: 32 fresh draws of weights and inputs (C=8, 64x64, batch 2) x 3 teacher-forced steps.  For every
+    (draw, step) the oracle (oracle/restatement.py, pinned to the reference's own modules at 1e-5) runs the step in fp64 -- that
+    trajectory supplies the state each step starts from (parameters, Adam moments, spectral-norm vectors) and the exact
+    gradients -- and then, from that same state, (a) the oracle in fp32 on the host and (b) the HIP step; the sample is the
+    aggregate relative L2 distance of the generator gradients from the fp64 ones (enhanced_train.py:59-131).
+
+    Assertions (the discriminator gradients have no flip noise: plain 3x bar):
+      * systematic error: a small systematic backward error would put a FLOOR under the HIP distances that a correct fp32
+        implementation's well-conditioned draws do not have (the oracle-fp32's 10th percentile is ~2e-4: no mask flips there).
+        The third-smallest of the 96 HIP samples must be <= max(3e-4, 1.5 x the oracle-fp32's third-smallest): a pin three times
+        below the 1e-3 north-star tolerance that flip noise cannot fake and that does not depend on the luck of one draw;
+      * spread: median and 90th percentile of HIP <= 1.25 x the oracle-fp32's, pooled (n = 96) and per step (n = 32) -- or inside
+        the sampling noise of that ratio where 1.25 is below it: the two implementations flip DIFFERENT masks on the same draw,
+        and the ratio of two sample quantiles of this heavy-tailed distribution (p90 / p10 ~ 100) scatters by more than 1.25x at
+        these n.  The allowance is the 99.9th percentile of the same ratio under random relabelling of the paired samples (a
+        paired permutation test with a fixed seed; every number is printed)."""
+    from fp64_fixture import LOSS_KEYS
+    from oracle import restatement as R
+    C, shape, ndraw, nstep = 8, (2, 3, 64, 64), 32, 3
+    model, _ = _build_cyclegan(C, [1, 2, 3, 4])
+    opts = {"g": model.g_optimizer, "d": model.d_optimizer}
+    nets = {"G_AB": model.G_AB, "G_BA": model.G_BA, "D_A": model.D_A, "D_B": model.D_B}
+    names = {"g": [n for m in (model.G_AB, model.G_BA) for n, _ in m.named_parameters()],
+             "d": [n for m in (model.D_A, model.D_B) for n, _ in m.named_parameters()]}
+    captured = {}
+    for which, opt in opts.items():
+        def step(_w=which, _opt=opt):  # gradients only: every step starts from a forced state, nothing is updated here ...
+            captured[_w] = _opt.grad.clone()
+            if _w == "d":
+                type(_opt).step(_opt)  # ... except the discriminator update INSIDE the step, which the generator loss sees
+        opt.step = step
+
+    def scatter(opt, flat, tensors):
+        with torch.no_grad():
+            for off, prm, t in zip(opt.offsets, opt.params, tensors):
+                flat[off:off + prm.numel()].copy_(t.reshape(-1).to(torch.float32))
+
+    def oracle_grads(orc, a, b, apply_g=False):
+        got = {}
+        d_step, g_step = orc.d_opt.step, orc.g_opt.step
+        orc.d_opt.step = lambda grads: (got.__setitem__("d", [None if t is None else t.detach().clone() for t in grads]), d_step(grads))
+        orc.g_opt.step = lambda grads: (got.__setitem__("g", [None if t is None else t.detach().clone() for t in grads]),
+                                        g_step(grads) if apply_g else None)
+        try:
+            losses = orc.train_step(a, b)
+        finally:
+            orc.d_opt.step, orc.g_opt.step = d_step, g_step
+        return got, losses
+
+    def distance(which, ours, refs):
+        num = den = 0.0
+        for n, mine, r in zip(names[which], ours, refs):
+            if r is None or dead_bias(n):
+                continue
+            num += float((mine.double().reshape(-1) - r.double().reshape(-1)).pow(2).sum())
+            den += float(r.double().pow(2).sum())
+        return (num / max(den, 1e-300)) ** 0.5
+
+    dist = {("g", "hip"): [], ("g", "f32"): [], ("d", "hip"): [], ("d", "f32"): []}
+    loss_err = 0.0
+    for d in range(ndraw):
+        seeds = [5000 + 10 * d + j for j in range(4)]
+        sds = [R.make_state_dict(R.generator_spec(C), seeds[0]), R.make_state_dict(R.generator_spec(C), seeds[1]),
+               R.make_state_dict(R.discriminator_spec(C), seeds[2]), R.make_state_dict(R.discriminator_spec(C), seeds[3])]
+        o64 = R.CycleGANOracle(*[{k: v.double() for k, v in sd.items()} for sd in sds])
+        assert [k for _, k in o64.g_keys] == names["g"] and [k for _, k in o64.d_keys] == names["d"]
+        for k in range(nstep):
+            a, b = R.make_input(shape, 7000 + 100 * d + 2 * k), R.make_input(shape, 7001 + 100 * d + 2 * k)
+            # the state this step starts from, as the fp64 trajectory holds it
+            sd64 = [{key: v.detach().clone() for key, v in sd.items()} for sd in (o64.G_AB, o64.G_BA, o64.D_A, o64.D_B)]
+            adam = {w: ([t.clone() for t in o.m], [t.clone() for t in o.v], list(o.t)) for w, o in (("g", o64.g_opt), ("d", o64.d_opt))}
+            # (a) oracle fp32 from that state
+            o32 = R.CycleGANOracle(*[{key: v.float() for key, v in sd.items()} for sd in sd64])
+            for w, o in (("g", o32.g_opt), ("d", o32.d_opt)):
+                o.m, o.v, o.t = [t.float() for t in adam[w][0]], [t.float() for t in adam[w][1]], list(adam[w][2])
+            g32, _ = oracle_grads(o32, a, b)
+            # (b) HIP from that state
+            for (name, net), sd in zip(nets.items(), sd64):
+                st = net.state_dict()
+                with torch.no_grad():
+                    for key, v in sd.items():
+                        st[key].copy_(v.to(torch.float32))
+            for w, opt in opts.items():
+                scatter(opt, opt.exp_avg, adam[w][0])
+                scatter(opt, opt.exp_avg_sq, adam[w][1])
+                opt.step_count = k
+            out = model.train_step(a.to(DEV), b.to(DEV))
+            # exact: this advances the fp64 trajectory
+            g64, l64 = oracle_grads(o64, a.double(), b.double(), apply_g=True)
+            loss_err = max(loss_err, max(abs(out[key] - l64[key]) / max(1.0, abs(l64[key])) for key in LOSS_KEYS))
+            for w, opt in opts.items():
+                ours = captured[w].cpu()
+                mine = [ours[off:off + prm.numel()] for off, prm in zip(opt.offsets, opt.params)]
+                dist[(w, "hip")].append((k, distance(w, mine, g64[w])))
+                dist[(w, "f32")].append((k, distance(w, g32[w], g64[w])))
+        print(f"  [parity] draw {d:2d}: g-gradient distance from fp64 per step  HIP " + " ".join(f"{v:.1e}" for _, v in dist[("g", "hip")][-nstep:])
+              + "   oracle-fp32 " + " ".join(f"{v:.1e}" for _, v in dist[("g", "f32")][-nstep:]), flush=True)
+
+    def q(vals, pct):
+        return float(np.percentile(np.asarray(vals, dtype=np.float64), pct))
+
+    def allowance(hip, f32, pct, rng):
+        """99.9th percentile of quantile(hip') / quantile(f32') over random swaps of the paired samples"""
+        hip, f32 = np.asarray(hip), np.asarray(f32)
+        r = []
+        for _ in range(5000):
+            sw = rng.random(len(hip)) < 0.5
+            r.append(np.percentile(np.where(sw, f32, hip), pct) / np.percentile(np.where(sw, hip, f32), pct))
+        return float(np.percentile(r, 99.9))
+
+    rng = np.random.default_rng(1234)
+    print(f"  [parity] distribution test: worst loss distance from fp64 over {ndraw * nstep} forced steps {loss_err:.2e}")
+    assert loss_err <= 5e-3
+    hip_all, f32_all = sorted(v for _, v in dist[("g", "hip")]), sorted(v for _, v in dist[("g", "f32")])
+    print(f"  [parity] g-gradient distance from fp64, three smallest of {len(hip_all)}: HIP {hip_all[:3]}  oracle-fp32 {f32_all[:3]}")
+    assert hip_all[2] <= max(3e-4, 1.5 * f32_all[2]), ("floor under the HIP distances", hip_all[:3], f32_all[:3])
+    for sel, tag in [(None, "pooled")] + [(k, f"step {k}") for k in range(nstep)]:
+        hip = [v for kk, v in dist[("g", "hip")] if sel is None or kk == sel]
+        f32 = [v for kk, v in dist[("g", "f32")] if sel is None or kk == sel]
+        line = f"  [parity] g-gradient distance from fp64, {tag:7s} (n={len(hip)}):"
+        for pct in (10, 50, 90):
+            line += f"  p{pct} HIP {q(hip, pct):.2e} / oracle-fp32 {q(f32, pct):.2e}"
+        print(line)
+        for pct in (50, 90):
+            ratio, allow = q(hip, pct) / q(f32, pct), max(1.25, allowance(hip, f32, pct, rng))
+            print(f"  [parity]     p{pct} ratio {ratio:.2f} (bar 1.25; sampling allowance at this n {allow:.2f})")
+            assert ratio <= allow, (tag, pct, ratio, allow)
+    dh, d3 = [v for _, v in dist[("d", "hip")]], [v for _, v in dist[("d", "f32")]]
+    print(f"  [parity] d-gradient distance from fp64: max HIP {max(dh):.2e} / oracle-fp32 {max(d3):.2e}")
+    assert max(dh) <= max(1e-4, 3.0 * max(d3))
 
 
 def test_train_step_gradients_vs_oracle():

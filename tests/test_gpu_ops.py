@@ -226,7 +226,8 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
 
 @pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
                                  "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0",
-                                 "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1"])
+                                 "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1",
+                                 "MSTG_ATTN_REG=0"])
 def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
@@ -245,6 +246,12 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     if k == "MSTG_ATTN_BLK4":
         for shape in ((2, 8, 8, 128), (1, 4, 8, 256), (1, 8, 4, 96), (1, 4, 4, 200)):
             test_window_attention_core(*shape)
+    if k == "MSTG_ATTN_REG":  # the LDS-tile fused attention kernels of rounds 1-2 behind the register-resident ones
+        for shape in ((2, 8, 12, 16), (1, 16, 16, 32), (1, 64, 64, 16)):
+            test_local_attention_fused_vs_oracle(*shape)
+        import test_gpu_normfuse
+        test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(16, 3, 16, 24)
+        test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(32, 2, 24, 16)
 
 
 NORM_CASES = [(2, 16, 24, 8, 1), (1, 64, 64, 16, 1), (3, 7, 9, 32, 2), (2, 4, 4, 64, 2), (1, 128, 128, 16, 1), (2, 2, 2, 64, 2),

@@ -55,3 +55,18 @@ def test_dataset_item_and_output_conversion_restatements():
     out = IR.process_cyclegan_ref(lambda x: -x, img)  # "model" = colour inversion: the geometry must survive the round trip
     assert out.shape == img.shape
     assert np.array_equal(out, IR.process_cyclegan_ref(lambda x: -x, img, resize=IR.resample_numpy))
+
+
+def test_blend_restatements():
+    """batch_process_images.py:304-312, :340-342: the numpy expressions themselves (float64 products, clip, truncation)."""
+    a = np.array([[[0, 10, 255]], [[200, 100, 50]]], dtype=np.uint8)
+    b = np.array([[[255, 20, 0]], [[100, 200, 250]]], dtype=np.uint8)
+    out = IR.blend_simple(a, b, 0.8)
+    assert out.dtype == np.uint8 and out.tolist() == [[[204, 18, 50]], [[120, 180, 210]]]  # 255 * (1 - 0.8) = 50.99999999999999 in float64: truncation gives 50
+    assert np.array_equal(IR.blend_simple(a, b, 0.0), a) and np.array_equal(IR.blend_simple(a, b, 1.0), b)
+    wm = np.array([[0.0], [1.0]])
+    assert np.array_equal(IR.blend_weight_map(a, b, wm)[0], a[0]) and np.array_equal(IR.blend_weight_map(a, b, wm)[1], b[1])
+    assert np.array_equal(IR.blend_weight_map(a, b, np.full((2, 1), 0.8)), out)
+    img = _img(120, 200, 9)
+    res = IR.process_local_style_ref(lambda x: -x, img, mode="simple", strength=0.5)
+    assert res.shape == img.shape and res.dtype == np.uint8
