@@ -69,6 +69,18 @@ typedef struct mstg_conv_desc {
     int32_t accumulate;     /* fwd: y += result; dgrad: dx += result (branches that share an input) */
 } mstg_conv_desc;
 
+/* Input gradient of a convolution whose INPUT was y = ReLU(InstanceNorm2d(x_raw)) (enhanced_generator.py:93-94, 72-75 + 84: the
+ * stem norm in front of down1, a MultiScaleBlock's concat norm in front of its fusion convolution, a block's fusion norm in front
+ * of the next stage's convolution): besides dx = dL/dy the launch emits sums[n][0][c] = sum_p dx [x^ > 0] and sums[n][1][c] =
+ * sum_p dx [x^ > 0] x^ (x^ = (x_raw - mean) * rstd from x_stats [N][Cin][2]) from its epilogue -- the two reductions of that norm's
+ * backward, which mstg_norm_bwd_apply(..., sums, 1, ...) consumes; the statistics pass over (x_raw, dx) is not needed.  Supported
+ * where the persistent kernel runs the input gradient (mstg_conv2d_dgrad_bsums_supported); workspace_packed as for the *_cached
+ * entry points below. */
+int mstg_conv2d_dgrad_bsums_supported(const mstg_conv_desc* d);
+size_t mstg_conv2d_dgrad_bsums_workspace_bytes(const mstg_conv_desc* d);
+int mstg_conv2d_dgrad_bsums(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, const float* x_raw, const float* x_stats,
+                            float* sums, void* workspace, size_t workspace_bytes, int workspace_packed, void* stream);
+
 /* Filter-pack caching.  mstg_conv2d_fwd / _fwd_norm / _dgrad and mstg_msblock_fwd / _dgrad begin by re-packing the filter into the
  * caller's workspace (a ~5 us launch, ~170 of them per CycleGAN step).  The *_cached twins take workspace_packed: non-zero = "this
  * workspace still holds what the SAME call (same descriptor, same pass, same weight VALUES) packed into it", and the pack launch is

@@ -161,6 +161,11 @@ class EnhancedGenerator(nn.Module):
         Under ``torch.no_grad()`` ``forward`` then runs csrc/infer_f16.hip (mstg_hip/infer.py) and returns an fp16 (N,3,H,W)
         tensor; with autograd enabled the fp32 training path still runs.  The packed fp16 filters are rebuilt lazily after a
         ``load_state_dict``; call ``half_inference()`` again after changing weights in any other way."""
+        if enable:  # fail here, not at the first forward: the fp16 kernels are built for the deployed width
+            C0 = self.initial[0].out_channels
+            if C0 != 16:
+                raise RuntimeError(f"mstg_hip fp16 inference is built for channels=16 (stage widths 16/32/64, what every trainer and "
+                                   f"inference caller of the reference uses), got channels={C0}; the fp32 forward serves other widths")
         self._half_enabled = bool(enable)
         self._half_plan = None
         if enable and not getattr(self, "_half_hook", False):

@@ -128,6 +128,11 @@ class EnhancedCycleGAN:
     # generators' forward+backward 35.9 -> 31.6 ms; whole step 64.9 -> 54.9 ms).  Autograd runs every backward node on the
     # stream of its forward, so the assignment holds for the backward too; each parameter's gradient is only ever touched
     # from one stream.
+    def _update_stream(self):
+        if getattr(self, "_upd_stream", None) is None:
+            self._upd_stream = torch.cuda.Stream(device=self.device)
+        return self._upd_stream
+
     def _side_streams(self):
         if getattr(self, "_streams", None) is None:
             self._streams = tuple(torch.cuda.Stream(device=self.device) for _ in range(4))
@@ -206,9 +211,17 @@ class EnhancedCycleGAN:
         d_fake_loss = (dA_fake + dB_fake) * 0.5
         d_loss = d_real_loss + d_fake_loss
         d_loss.backward()
-        join_backward()
-        dp.allreduce_mean_(self.d_optimizer.grad)
-        self.d_optimizer.step()
+        # The discriminator exchange + update (one all-reduce over the flat gradient buffer, one fused Adam launch) runs on a
+        # stream of its own: in the generator phase only the discriminator forwards depend on it, so the two cycle reconstructions
+        # (the largest launches of the step) start at once instead of waiting out the collective's latency on xGMI.
+        upd = self._update_stream() if two else main
+        if two:
+            upd.wait_stream(main)
+            for st in side:
+                upd.wait_stream(st)  # the weight-gradient kernels of this backward ran on the side streams of their forwards
+        with on(upd):
+            dp.allreduce_mean_(self.d_optimizer.grad)
+            self.d_optimizer.step()
         # ---- generator update (reference :88-123); D weights take no gradient here (it would be discarded)
         self.g_optimizer.zero_grad(set_to_none=True)
         for p in self._d_params:
@@ -229,8 +242,18 @@ class EnhancedCycleGAN:
             with on(sA):
                 recon_B = G_AB(fake_A)
                 cB = ops.l1_loss(recon_B, real_B)
-            # enqueue order: stream A gets its large reconstruction first and its discriminator's small launches second,
-            # stream B the other way round, so that small work overlaps large work rather than small with small
+            # enqueue order on one GPU: stream A gets its large reconstruction first and its discriminator's small launches second,
+            # stream B the other way round, so that small work overlaps large work rather than small with small.  With more than
+            # one rank both streams start with their reconstruction: the discriminator passes wait for the update stream (the
+            # all-reduce), the reconstructions do not.
+            recon_first = dp.world_size() > 1
+            if recon_first:
+                with on(sB):
+                    recon_A = G_BA(fake_B)
+                    cA = ops.l1_loss(recon_A, real_A)
+            if two:
+                sC.wait_stream(upd)
+                sD.wait_stream(upd)
             with on(sD):
                 fake_B_score, fake_B_struct = D_B(fake_B)
                 gB = ops.mse_to_const(fake_B_score, 1.0)
@@ -238,9 +261,10 @@ class EnhancedCycleGAN:
                     _, real_B_struct = D_B(real_B)
                 _, fake_B_struct = D_B(fake_B)
                 sB_l = ops.l1_loss(real_B_struct, fake_B_struct)
-            with on(sB):
-                recon_A = G_BA(fake_B)
-                cA = ops.l1_loss(recon_A, real_A)
+            if not recon_first:
+                with on(sB):
+                    recon_A = G_BA(fake_B)
+                    cA = ops.l1_loss(recon_A, real_A)
             with on(sC):
                 fake_A_score, fake_A_struct = D_A(fake_A)
                 gA = ops.mse_to_const(fake_A_score, 1.0)
@@ -294,7 +318,11 @@ class EnhancedCycleGAN:
                              (f"discriminators_epoch_{epoch}.pth", (("D_A_state_dict", self.D_A), ("D_B_state_dict", self.D_B)))):
             ckpt = torch.load(save_path / fname, map_location=self.device, weights_only=True)
             for key, module in pairs:
-                module.load_state_dict(ckpt[key], strict=True)
+                # a file convert_model.py has flattened (convert_model.py:12-29) holds the bare state dict of its one network
+                sd = ckpt[key] if isinstance(ckpt, dict) and key in ckpt else (ckpt if len(pairs) == 1 else None)
+                if sd is None:
+                    raise KeyError(f"{fname}: no '{key}' entry")
+                module.load_state_dict(sd, strict=True)
         return epoch
 
 

@@ -41,6 +41,9 @@ SIGNATURES = {
     "mstg_conv2d_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_conv2d_dgrad": (_i, [_dp, _fp, _fp, _fp, _vp, _sz, _vp]),
+    "mstg_conv2d_dgrad_bsums_supported": (_i, [_dp]),
+    "mstg_conv2d_dgrad_bsums_workspace_bytes": (_sz, [_dp]),
+    "mstg_conv2d_dgrad_bsums": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
     "mstg_conv2d_fwd_cached": (_i, [_dp, _fp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
     "mstg_conv2d_fwd_norm_cached": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),
     "mstg_conv2d_dgrad_cached": (_i, [_dp, _fp, _fp, _fp, _vp, _sz, _i, _vp]),

@@ -1197,6 +1197,36 @@ extern "C" int mstg_conv2d_dgrad(const mstg_conv_desc* d, const float* dy, const
     return launch_igemm(a, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// ---- input gradient + the reductions of the norm backward it feeds (conv_p32.hip, STATS == 2) ----------------------------------------
+extern "C" int mstg_conv2d_dgrad_bsums_supported(const mstg_conv_desc* d) {
+    if (check_desc(d)) return 0;
+    IGemmArgs a{};
+    if (fill_dgrad_args(d, a)) return 0;
+    return p32_generic(a) && a.Co != 1 && !d->accumulate && d->x_ctot == d->Cin && d->x_coff == 0 ? 1 : 0;
+}
+
+extern "C" size_t mstg_conv2d_dgrad_bsums_workspace_bytes(const mstg_conv_desc* d) {
+    if (!mstg_conv2d_dgrad_bsums_supported(d)) return 0;
+    IGemmArgs a{};
+    fill_dgrad_args(d, a);
+    return p32_norm_workspace_bytes(a);
+}
+
+extern "C" int mstg_conv2d_dgrad_bsums(const mstg_conv_desc* d, const float* dy, const float* w, float* dx, const float* x_raw,
+                                       const float* x_stats, float* sums, void* workspace, size_t workspace_bytes, int workspace_packed,
+                                       void* stream) {
+    if (int rc = check_desc(d)) return rc;
+    if (!dy || !w || !dx || !x_raw || !x_stats || !sums) return fail_arg(MSTG_E_BADARG, "conv_dgrad_bsums: null pointer");
+    if (!mstg_conv2d_dgrad_bsums_supported(d)) return fail_arg(MSTG_E_UNSUPPORTED, "conv_dgrad_bsums: only the layers mstg_conv2d_dgrad_bsums_supported() reports");
+    IGemmArgs a{};
+    if (int rc = fill_dgrad_args(d, a)) return rc;
+    a.x = dy; a.y = dx; a.w = w; a.bias = nullptr;
+    mstg::t_ws_packed = workspace_packed != 0;
+    const int rc = launch_p32_bsums(a, x_raw, x_stats, sums, workspace, workspace_bytes, (hipStream_t)stream);
+    mstg::t_ws_packed = false;
+    return rc;
+}
+
 // ---- the same entry points for a caller that caches filter packs (common.h: t_ws_packed) -------------------------------------------
 namespace {
 struct PackedScope {

@@ -47,6 +47,8 @@ struct P32Args {
     const float* in_stats;  // nullable [N][Cin][2] (mean, rstd): the source is normalised + ReLU'd while it is staged
     float* partial;         // STATS kernels: [N][workgroups][2][16 * NF] sums / sums of squares of what the workgroup wrote; only the
                             // (image, workgroup) pairs that meet are written -- and read
+    const float* aux;       // STATS == 2 (input-gradient launch in front of an InstanceNorm + ReLU): the RAW tensor that norm
+    const float* aux_stats; // normalised, same shape as this launch's output, and its (mean, rstd) [N][Cout][2]
     int N, H, W, Cin, Ho, Wo, Cout, Gh, Gw, tiles_x, tiles_y, dbg;
 };
 
@@ -117,7 +119,10 @@ __device__ __forceinline__ float p32_row16_sum(float v) {
 // STATS: the epilogue also sums what it stores (InstanceNorm statistics of the output without another pass over it); a.in_stats:
 // the source is the RAW tensor in front of an InstanceNorm + ReLU, normalised while the patch is committed to LDS (zero padding
 // applies to the normalised tensor, as in the reference where the convolution pads what the norm produced).
-template <int RPW, int NF, int NPF, bool WLDS, bool STATS>
+// STATS == 2: the launch computes an input gradient dz whose consumer is the backward of y = ReLU(InstanceNorm(f)) (dz = dL/dy);
+// the epilogue re-reads f (a.aux) at the pixels it stores and sums, per (image, channel), g = dz [f^ > 0] and g f^ -- the two
+// reductions that norm backward needs (norm_partial_kernel<true> read f and dz once more for them).
+template <int RPW, int NF, int NPF, bool WLDS, int STATS>
 __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P32Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 4 * RPW;
@@ -183,6 +188,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         __syncthreads();
     };
     int cur_n = -1;
+    f32x4 amu[STATS == 2 ? NF : 1], ars[STATS == 2 ? NF : 1];  // STATS == 2: (mean, rstd) of the lane's output channels, image cur_n
     float nsc[4], nnb[4];  // in_stats: (rstd, mean) of this thread's channel quad of image cur_in
     int cur_in = -1;
     const size_t out_row = (size_t)(up ? 2 : 1) * a.Wo * a.Cout * 4;  // bytes between this wave's consecutive rows
@@ -203,6 +209,15 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
         if (STATS && n != cur_n) {
             if (cur_n >= 0) flush_stats(cur_n);
             cur_n = n;
+            if (STATS == 2) {
+#pragma unroll
+                for (int f = 0; f < (STATS == 2 ? NF : 1); ++f) {
+                    const float* st = a.aux_stats + ((size_t)n * a.Cout + 16 * f + 4 * g) * 2;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1_ = *reinterpret_cast<const f32x4*>(st + 4);
+                    amu[f] = f32x4{s0[0], s0[2], s1_[0], s1_[2]};
+                    ars[f] = f32x4{s0[1], s0[3], s1_[1], s1_[3]};
+                }
+            }
         }
         if (a.in_stats && n != cur_in) {
             const float* st = a.in_stats + ((size_t)n * a.Cin + 4 * o) * 2;
@@ -272,18 +287,41 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             const int mul = up ? 2 : 1;
             if (a.dbg & 2) continue;
             if (gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw && (a.Cout & 15) == 0) {
-                char* ybase = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
+                const size_t ybyte = ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
+                char* ybase = reinterpret_cast<char*>(a.y) + ybyte;
                 const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 4u;
+                f32x4 av[STATS == 2 ? RPW : 1][STATS == 2 ? NF : 1];
+                if (STATS == 2) {  // all of this wave's f loads in flight before the stores go out
+                    const char* abase = reinterpret_cast<const char*>(a.aux) + ybyte;
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) av[STATS == 2 ? r : 0][STATS == 2 ? f : 0] = *reinterpret_cast<const f32x4*>(abase + r * out_row + out_off0 + 64 * f);
+                }
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
-                        if (STATS) {
+                        if (STATS == 1) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
                         }
                         *reinterpret_cast<f32x4*>(ybase + r * out_row + out_off0 + 64 * f) = acc[r][f];
                     }
+                if (STATS == 2) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const f32x4 xh = (av[STATS == 2 ? r : 0][STATS == 2 ? f : 0] - amu[STATS == 2 ? f : 0]) * ars[STATS == 2 ? f : 0];  // norm_partial_kernel<true>'s arithmetic
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float gg = xh[q] > 0.f ? acc[r][f][q] : 0.f;
+                                ssum[f][q] += gg;
+                                ssq[f][q] += gg * xh[q];
+                            }
+                        }
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
@@ -293,11 +331,21 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
 #pragma unroll
                         for (int f = 0; f < NF; ++f)
                             if (16 * f + 4 * g < a.Cout) {
-                                if (STATS) {
+                                const size_t oe = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g;
+                                if (STATS == 1) {
 #pragma unroll
                                     for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
                                 }
-                                *reinterpret_cast<f32x4*>(a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g) = acc[r][f];
+                                if (STATS == 2) {
+                                    const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.aux + oe) - amu[STATS == 2 ? f : 0]) * ars[STATS == 2 ? f : 0];
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float gg = xh[q] > 0.f ? acc[r][f][q] : 0.f;
+                                        ssum[f][q] += gg;
+                                        ssq[f][q] += gg * xh[q];
+                                    }
+                                }
+                                *reinterpret_cast<f32x4*>(a.y + oe) = acc[r][f];
                             }
                     }
                 }
@@ -334,6 +382,30 @@ __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __r
         if (var < 0.0) var = 0.0;
         stats[((size_t)n * C + c) * 2] = (float)mean;
         stats[((size_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// STATS == 2: partial [N][G][2][CP] -> sums [N][2][C] (what norm_apply_kernel<true> reads with one row per image); same row
+// selection and fixed order as above
+__global__ __launch_bounds__(256) void p32_bsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int G, int CP,
+                                                                int C, int ntile, int chunk) {
+    __shared__ double red[256 * 2];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int per_c = 256 / CP, c = tid % CP, sub = tid / CP;
+    const int b_lo = (int)(((long)n * ntile) / chunk), b_hi = (int)((((long)n + 1) * ntile - 1) / chunk);
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = b_lo + sub; b <= b_hi && b < G; b += per_c) {
+        const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
+        s1 += (double)pp[c];
+        s2 += (double)pp[CP + c];
+    }
+    red[tid * 2] = s1;
+    red[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (sub == 0 && c < C) {
+        for (int k = 1; k < per_c; ++k) { s1 += red[(k * CP + c) * 2]; s2 += red[(k * CP + c) * 2 + 1]; }
+        sums[(size_t)n * 2 * C + c] = (float)s1;
+        sums[(size_t)n * 2 * C + C + c] = (float)s2;
     }
 }
 
@@ -910,14 +982,16 @@ size_t p32_workspace_bytes(const IGemmArgs& a) {
 
 template <int RPW, int NF, int NPF>
 static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hipStream_t st, float* out_stats) {
-    auto kern = out_stats ? (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, true> : conv_p32_kernel<RPW, NF, NPF, false, true>)
-                          : (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, false> : conv_p32_kernel<RPW, NF, NPF, false, false>);
+    const int mode = !out_stats ? 0 : (a.aux ? 2 : 1);
+    auto kern = mode == 2 ? (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, 2> : conv_p32_kernel<RPW, NF, NPF, false, 2>)
+              : mode == 1 ? (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, 1> : conv_p32_kernel<RPW, NF, NPF, false, 1>)
+                          : (p.wlds ? conv_p32_kernel<RPW, NF, NPF, true, 0> : conv_p32_kernel<RPW, NF, NPF, false, 0>);
     const void* kptr = reinterpret_cast<const void*>(kern);
     // persistent workgroups: what a CU really holds of this kernel at this LDS size (registers, LDS), at most 4.  One slot per
     // (filter in LDS, statistics) variant; a race between threads recomputes the same value.
-    static size_t c_lds_tab[4] = {0, 0, 0, 0};
-    static int c_occ_tab[4] = {0, 0, 0, 0};
-    const int slot = (p.wlds ? 1 : 0) + (out_stats ? 2 : 0);
+    static size_t c_lds_tab[6] = {0, 0, 0, 0, 0, 0};
+    static int c_occ_tab[6] = {0, 0, 0, 0, 0, 0};
+    const int slot = (p.wlds ? 1 : 0) + 2 * mode;
     if (!c_occ_tab[slot] || c_lds_tab[slot] != lds) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(kptr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         int nb = 1;
@@ -931,7 +1005,12 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
     if (g_ > tiles) g_ = (tiles + 7) & ~7L;
     MSTG_LAUNCH(kern, dim3((unsigned)g_), dim3(256), lds, st, a, p);
     MSTG_CHECK_LAUNCH("conv_p32_kernel");
-    if (out_stats) {
+    if (mode == 2) {
+        const int ntile = a.tiles_x * a.tiles_y;
+        MSTG_LAUNCH(p32_bsum_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout, ntile,
+                    (int)((tiles + g_ - 1) / g_));
+        MSTG_CHECK_LAUNCH("p32_bsum_finalize_kernel");
+    } else if (out_stats) {
         const int ntile = a.tiles_x * a.tiles_y;
         MSTG_LAUNCH(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
                            (float)((size_t)a.Ho * a.Wo), ntile, (int)((tiles + g_ - 1) / g_));
@@ -955,7 +1034,29 @@ size_t p32_norm_workspace_bytes(const IGemmArgs& g) {  // packed filter + statis
 
 int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipStream_t st) { return launch_p32_norm(g, nullptr, nullptr, workspace, workspace_bytes, st); }
 
+// the generic (non image-source, non packed-head) persistent kernel runs this launch: what the folded variants need
+bool p32_generic(const IGemmArgs& g) {
+    return p32_eligible(g) && !co1_eligible(g) && !p32i_eligible(g) && !p32d_eligible(g) && !g.x_nchw && !g.y_nchw;
+}
+
+static int launch_p32_full(const IGemmArgs& g, const float* in_stats, float* out_stats, const float* aux, const float* aux_stats,
+                           void* workspace, size_t workspace_bytes, hipStream_t st);
+
 int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    return launch_p32_full(g, in_stats, out_stats, nullptr, nullptr, workspace, workspace_bytes, st);
+}
+
+// input-gradient launch whose output dz feeds the backward of ReLU(InstanceNorm(aux)): sums [N][2][Cout] = per (image, channel)
+// sum of dz [aux^ > 0] and of dz [aux^ > 0] aux^ (workspace as for the statistics-emitting forward)
+int launch_p32_bsums(const IGemmArgs& g, const float* aux, const float* aux_stats, float* sums, void* workspace, size_t workspace_bytes,
+                     hipStream_t st) {
+    if (!aux || !aux_stats || !sums) return fail_arg(MSTG_E_BADARG, "conv_p32 bsums: null pointer");
+    if (!p32_generic(g)) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32 bsums: only the layers the generic persistent kernel runs");
+    return launch_p32_full(g, nullptr, sums, aux, aux_stats, workspace, workspace_bytes, st);
+}
+
+static int launch_p32_full(const IGemmArgs& g, const float* in_stats, float* out_stats, const float* aux, const float* aux_stats,
+                           void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (co1_eligible(g)) {
         if (in_stats || out_stats) return fail_arg(MSTG_E_UNSUPPORTED, "conv_co1: no InstanceNorm folding");
         return launch_co1(g, st);
@@ -974,6 +1075,8 @@ int launch_p32_norm(const IGemmArgs& g, const float* in_stats, float* out_stats,
     if (!workspace || workspace_bytes < need) return fail_arg(MSTG_E_WORKSPACE, "conv_p32: workspace too small for the packed filter");
     P32Args a;
     a.in_stats = in_stats;
+    a.aux = aux;
+    a.aux_stats = aux_stats;
     a.partial = out_stats ? (float*)((char*)workspace + ((256 + (size_t)p.nsteps * p.NF * 1024 + 255) & ~(size_t)255)) : nullptr;
     a.x = g.x; a.y = g.y;
     a.bias = (const float*)workspace;

@@ -127,8 +127,12 @@ class HalfGeneratorPlan:
         C0 = gen.initial[0].out_channels
         if C0 != 16:
             raise RuntimeError(f"mstg_hip fp16 inference is built for channels=16 (stage widths 16/32/64), got channels={C0}")
-        if any(not getattr(b, "is_identity", False) for b in gen.transformer_blocks):
-            raise RuntimeError("mstg_hip fp16 inference: transformer blocks are not part of the fp16 path")
+        # StructuralTransformerBlocks (every inference caller of the reference builds num_transformer_blocks=1:
+        # direct_transform.py:35, advanced_transform.py:29, batch_process_images.py:95) run on the fp32 kernels between down2 and up1:
+        # that tensor is H/4 x W/4 x 64 channels, 1/16 of the activation traffic, and the block's LayerNorm / softmax statistics
+        # want fp32 anyway.  The fp16 features are widened for it and narrowed again behind it.
+        self.blocks = [b for b in gen.transformer_blocks if not getattr(b, "is_identity", False)]
+        self.style_vector = gen._style_vector
         if gen.initial[0].weight.device.type != "cuda":
             raise RuntimeError("mstg_hip fp16 inference: move the generator to the GPU first (no CPU path)")
         c = gen.initial[0]
@@ -166,6 +170,14 @@ class HalfGeneratorPlan:
             stats = None
             if taps is not None:
                 taps[("down1", "down2", "up1", "up2")[si]] = h
+            if si == 1 and self.blocks:             # enhanced_generator.py:216-225: style vector, tokens, blocks, back
+                hf = h.float()
+                N, H4, W4, C4 = hf.shape
+                style = self.style_vector(hf)
+                tokens = hf.reshape(N, H4 * W4, C4)
+                for block in self.blocks:
+                    tokens = block(tokens, style, x)
+                h = tokens.reshape(N, H4, W4, C4).half()
         if taps is not None:
             taps["pre_tanh"] = self.head_pre(h)[0]
         return self.head(h)[0]

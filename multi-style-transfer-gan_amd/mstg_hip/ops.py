@@ -235,28 +235,35 @@ def _cached_ws(owners, kind, dkey, nbytes: int, device):
             or not all(t is None or isinstance(t, torch.nn.Parameter) for t in owners)):
         return _ws(nbytes, device), 0
     packs = owners[0].__dict__.setdefault("_mstg_packs", {})
-    key = (kind, dkey, torch.cuda.current_stream().cuda_stream)
+    key, stream = (kind, dkey), torch.cuda.current_stream().cuda_stream
     stamp = _pack_stamp(owners)
     ent = packs.get(key)
-    if ent is not None and ent[0].numel() * 4 >= nbytes:
+    if ent is not None and ent[2] == stream and ent[0].numel() * 4 >= nbytes:
         if ent[1] == stamp:
             return ent[0], 1
-        packs[key] = (ent[0], stamp)  # same stream: the re-pack is ordered behind every launch that still reads the old one
+        packs[key] = (ent[0], stamp, stream)  # same stream: the re-pack is ordered behind every launch that still reads the old one
         return ent[0], 0
+    # first use, or a use from ANOTHER stream than the last one (launches of the other stream may still read the old workspace:
+    # it is left alone and dropped; in steady state a layer always runs on the same stream)
     ws = _ws(nbytes, device)
-    packs[key] = (ws, stamp)
+    packs[key] = (ws, stamp, stream)
     return ws, 0
 
 
-def _dkey(d: ConvDesc):
-    return tuple(getattr(d, n) for n, _ in ConvDesc._fields_)
+def _dkey(d: ConvDesc, pass_: int):
+    """What a filter pack depends on.  The persistent kernels' packs (conv_p32.hip: p32_plan) are a function of the filter geometry
+    and channel chunking only, so the batch size is left out of the key there -- a generator's batched pass (2N images) and its
+    reconstruction pass (N images) share one pack per step; other kernels plan by tile count, their key keeps every field."""
+    fields = tuple(getattr(d, n) for n, _ in ConvDesc._fields_)
+    name = _lib.load().mstg_conv2d_kernel_name(C.byref(d), pass_)
+    return (name,) + (fields[1:] if name.startswith(b"conv_p32") else fields)
 
 
 def conv_fwd_raw(d: ConvDesc, x, w, b, y, owners=None):
     """owners: the (weight, bias) objects of the calling layer when it owns them (nn.Parameters) -> their pack is kept."""
     fl, by = _conv_cost(d)
     lib = _lib.load()
-    ws, packed = _cached_ws(owners, "fwd", _dkey(d), lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
+    ws, packed = _cached_ws(owners, "fwd", _dkey(d, 0), lib.mstg_conv2d_workspace_bytes(C.byref(d)), x.device)
     _timed(_kernel_name(d, 0), fl, by, lambda: _lib.check(
         lib.mstg_conv2d_fwd_cached(C.byref(d), _p(x), _p(w), _p(b), _p(y), _p(ws), ws.numel() * 4, packed, _stream()), "mstg_conv2d_fwd"),
         _conv_detail("fwd", d))
@@ -265,10 +272,44 @@ def conv_fwd_raw(d: ConvDesc, x, w, b, y, owners=None):
 def conv_dgrad_raw(d: ConvDesc, dy, w, dx, owners=None):
     fl, by = _conv_cost(d)
     lib = _lib.load()
-    ws, packed = _cached_ws(owners, "dgrad", _dkey(d), lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
+    ws, packed = _cached_ws(owners, "dgrad", _dkey(d, 1), lib.mstg_conv2d_workspace_bytes(C.byref(d)), dy.device)
     _timed(_kernel_name(d, 1), fl, by, lambda: _lib.check(
         lib.mstg_conv2d_dgrad_cached(C.byref(d), _p(dy), _p(w), _p(dx), _p(ws), ws.numel() * 4, packed, _stream()), "mstg_conv2d_dgrad"),
         _conv_detail("dgrad", d))
+
+
+def norm_bsums_enabled() -> bool:
+    """MSTG_NORM_BSUMS=0: the norm backward's two reductions come from its own statistics pass again (A/B, tests)."""
+    return os.environ.get("MSTG_NORM_BSUMS", "1") != "0"
+
+
+def conv_dgrad_bsums_supported(d: ConvDesc) -> bool:
+    return norm_bsums_enabled() and bool(_lib.load().mstg_conv2d_dgrad_bsums_supported(C.byref(d)))
+
+
+def conv_dgrad_bsums_raw(d: ConvDesc, dy, w, dx, x_raw, x_stats, owners=None):
+    """dx = input gradient of the convolution whose input was ReLU(InstanceNorm(x_raw)); returns sums (N, 1, 2, Cin): what that norm's
+    backward needs from a pass over (x_raw, dx), summed in this launch's epilogue instead (mstg_conv2d_dgrad_bsums)."""
+    fl, by = _conv_cost(d)
+    lib = _lib.load()
+    sums = torch.empty((d.N, 1, 2, d.Cin), dtype=torch.float32, device=dy.device)
+    ws, packed = _cached_ws(owners, "dgrad_bsums", _dkey(d, 1), lib.mstg_conv2d_dgrad_bsums_workspace_bytes(C.byref(d)), dy.device)
+    _timed(_kernel_name(d, 1), fl, by + 4 * x_raw.numel(), lambda: _lib.check(
+        lib.mstg_conv2d_dgrad_bsums(C.byref(d), _p(dy), _p(w), _p(dx), _p(x_raw), _p(x_stats), _p(sums), _p(ws), ws.numel() * 4, packed,
+                                    _stream()), "mstg_conv2d_dgrad_bsums"), _conv_detail("dgrad+bsums", d))
+    return sums
+
+
+class _NormToken:
+    """Identity of one InstanceNorm + ReLU application: travels forward on the norm's output tensor (``_mstg_norm``) to the
+    convolution that consumes it, and back on that convolution's input gradient (``_mstg_bsums``) to the norm's backward."""
+    __slots__ = ()
+
+
+def _tag_norm_output(y, x_raw, stats, token):
+    if token is not None:
+        y._mstg_norm = (x_raw, stats, token)
+    return y
 
 
 def conv_wgrad_raw(d: ConvDesc, x, dy, dw, db=None):
@@ -328,6 +369,7 @@ class ConvFn(torch.autograd.Function):
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed, x_nchw, y_nchw, act=act)
         conv_fwd_raw(d, x, w, b, y, owners=(w, b))
         ctx.cfg, ctx.dims, ctx.has_bias = cfg, (N, H, W, Cin, Ho, Wo, Cout), b is not None
+        ctx.norm_src = getattr(x, "_mstg_norm", None) if not x_nchw else None
         # the objects handed to apply() are nn.Parameters when the layer owns them; only their .grad slots are looked up through
         # these references in backward (see _grad_slot) -- the VALUES used there come from saved_tensors (version-checked)
         ctx.prefs = (w, b)
@@ -346,7 +388,12 @@ class ConvFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            conv_dgrad_raw(d, dy, w, dx, owners=(ctx.prefs[0],))
+            src = getattr(ctx, "norm_src", None)
+            if src is not None and conv_dgrad_bsums_supported(d):
+                # x was ReLU(InstanceNorm(src[0])): the reductions of that norm's backward come out of this launch's epilogue
+                dx._mstg_bsums = (conv_dgrad_bsums_raw(d, dy, w, dx, src[0], src[1], owners=(ctx.prefs[0],)), src[2])
+            else:
+                conv_dgrad_raw(d, dy, w, dx, owners=(ctx.prefs[0],))
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         fuse_db = want_db and ctx.needs_input_grad[1] and not transposed
         if ctx.needs_input_grad[1]:
@@ -396,13 +443,14 @@ class ConvStatsFn(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
         stats = torch.empty((N, Cout, 2), dtype=torch.float32, device=x.device)
         d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
-        ws, packed = _cached_ws((w, b), "fwd_norm", _dkey(d), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
+        ws, packed = _cached_ws((w, b), "fwd_norm", _dkey(d, 0), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), x.device)
         fl, by = _conv_cost(d)
         _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(  # the STATS instantiation
             lib.mstg_conv2d_fwd_norm_cached(C.byref(d), _p(x), None, _p(w), _p(b), _p(y), _p(stats), _p(ws), ws.numel() * 4, packed,
                                             _stream()), "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
         ctx.cfg, ctx.dims, ctx.has_bias = (k, stride, pad, dil, transposed, 0, 0, ACT_NONE), (N, H, W, Cin, Ho, Wo, Cout), b is not None
         ctx.prefs = (w, b)
+        ctx.norm_src = getattr(x, "_mstg_norm", None)
         ctx.save_for_backward(x, w, None)
         ctx.mark_non_differentiable(stats)
         return y, stats
@@ -440,7 +488,7 @@ class MSFusionFn(torch.autograd.Function):
         y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
         ystats = torch.empty((N, Cout, 2), dtype=torch.float32, device=cat.device)  # (mean, rstd) of y from the epilogue
         d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
-        ws2, packed = _cached_ws((w, b), "fwd_norm", _dkey(d), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
+        ws2, packed = _cached_ws((w, b), "fwd_norm", _dkey(d, 0), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
         fl, by = _conv_cost(d)
         _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(
             lib.mstg_conv2d_fwd_norm_cached(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), _p(ystats), _p(ws2), ws2.numel() * 4,
@@ -460,12 +508,18 @@ class MSFusionFn(torch.autograd.Function):
         dcat = dw = db = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(cat)
-            conv_dgrad_raw(d, dy, w, dz, owners=(ctx.prefs[0],))  # gradient w.r.t. the normalised concat
             dcat = torch.empty_like(cat)
-            ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
-            _timed("norm_apply_kernel<true>", 0, 4 * cat.numel() * 3, lambda: _lib.check(
-                lib.mstg_norm_act_bwd(_p(cat), _p(stats), _p(dz), _p(dcat), N, H * W, Cn, ACT_RELU, 0, None, None, None, None, _p(ws),
-                                      ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
+            if conv_dgrad_bsums_supported(d):  # gradient w.r.t. the normalised concat + the norm backward's reductions, one launch
+                sums = conv_dgrad_bsums_raw(d, dy, w, dz, cat, stats, owners=(ctx.prefs[0],))
+                _timed("norm_apply_kernel<true>", 0, 4 * cat.numel() * 3, lambda: _lib.check(
+                    lib.mstg_norm_bwd_apply(_p(cat), _p(stats), _p(dz), _p(sums), 1, _p(dcat), N, H * W, Cn, ACT_RELU, _stream()),
+                    "mstg_norm_bwd_apply"))
+            else:
+                conv_dgrad_raw(d, dy, w, dz, owners=(ctx.prefs[0],))
+                ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
+                _timed("norm_apply_kernel<true>", 0, 4 * cat.numel() * 3, lambda: _lib.check(
+                    lib.mstg_norm_act_bwd(_p(cat), _p(stats), _p(dz), _p(dcat), N, H * W, Cn, ACT_RELU, 0, None, None, None, None, _p(ws),
+                                          ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
         if ctx.needs_input_grad[1]:
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             gw = _grad_slot(ctx.prefs[0])
@@ -510,7 +564,7 @@ class MSBranchesFn(torch.autograd.Function):
         y = torch.empty((N, H, W, 4 * c4), dtype=torch.float32, device=x.device)
         lib = _lib.load()
         if os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch:
-            wsb, packed = _cached_ws(tuple(wb), "ms_fwd", (N, H, W, ch), lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
+            wsb, packed = _cached_ws(tuple(wb), "ms_fwd", (ch,), lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
             wb_ptrs = []
             for j in range(4):
                 wb_ptrs += [_p(ws[j]), _p(bs[j])]
@@ -541,7 +595,7 @@ class MSBranchesFn(torch.autograd.Function):
         fused = os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch
         grads = []
         if fused and dx is not None:  # dx of all four branches in one pass over dy, written once
-            wsd, packed = _cached_ws(tuple(ctx.prefs[0::2]), "ms_dgrad", (N, H, W, ch), lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
+            wsd, packed = _cached_ws(tuple(ctx.prefs[0::2]), "ms_dgrad", (ch,), lib.mstg_msblock_dgrad_workspace_bytes(ch), x.device)
             _timed(f"ms_dgrad_kernel<{ch}>", 2.0 * N * H * W * ch * c4 * 28, 4.0 * (2 * N * H * W * ch),
                    lambda: _lib.check(lib.mstg_msblock_dgrad_cached(_p(dy), *[_p(t) for t in ws], _p(dres), _p(dx), N, H, W, ch, _p(wsd),
                                                                     wsd.numel() * 4, packed, _stream()), "mstg_msblock_dgrad"),
@@ -582,8 +636,9 @@ class InstNormActFn(torch.autograd.Function):
     """y = act(InstanceNorm2d(x)) [+ residual], NHWC."""
 
     @staticmethod
-    def forward(ctx, x, residual, act):
+    def forward(ctx, x, residual, act, token=None):
         lib = _lib.load()
+        ctx.token = token
         x = _req(x, "norm input")
         residual = None if residual is None else _req(residual, "norm residual")
         N, H, W, Cn = x.shape
@@ -595,7 +650,10 @@ class InstNormActFn(torch.autograd.Function):
                                   _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_fwd"))
         ctx.act, ctx.has_res = act, residual is not None
         ctx.save_for_backward(x, stats)
+        InstNormActFn.last_stats = stats if token is not None else None  # for instnorm_act() to tag y with (see _NormToken)
         return y
+
+    last_stats = None
 
     @staticmethod
     def backward(ctx, dy):
@@ -606,15 +664,31 @@ class InstNormActFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
-            _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
-                lib.mstg_norm_act_bwd(_p(x), _p(stats), _p(dy), _p(dx), N, H * W, Cn, ctx.act, 0, None, None, None, None,
-                                      _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
-        return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None
+            got = getattr(dy, "_mstg_bsums", None)
+            if got is not None and getattr(ctx, "token", None) is not None and got[1] is ctx.token and ctx.act == ACT_RELU:
+                # the consumer convolution's input-gradient launch already summed what this backward reduces (ConvFn.backward)
+                _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
+                    lib.mstg_norm_bwd_apply(_p(x), _p(stats), _p(dy), _p(got[0]), 1, _p(dx), N, H * W, Cn, ACT_RELU, _stream()),
+                    "mstg_norm_bwd_apply"))
+            else:
+                ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), x.device)
+                _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
+                    lib.mstg_norm_act_bwd(_p(x), _p(stats), _p(dy), _p(dx), N, H * W, Cn, ctx.act, 0, None, None, None, None,
+                                          _p(ws), ws.numel() * 4, _stream()), "mstg_norm_act_bwd"))
+        return dx, (dy if ctx.has_res and ctx.needs_input_grad[1] else None), None, None
+
+
+def _norm_token(act):
+    return _NormToken() if act == ACT_RELU and norm_bsums_enabled() and torch.is_grad_enabled() else None
 
 
 def instnorm_act(x, act=ACT_RELU, residual=None):
-    return InstNormActFn.apply(x, residual, act)
+    token = _norm_token(act)
+    y = InstNormActFn.apply(x, residual, act, token)
+    if token is not None:
+        _tag_norm_output(y, x, InstNormActFn.last_stats, token)
+        InstNormActFn.last_stats = None
+    return y
 
 
 class InstNormApplyFn(torch.autograd.Function):
@@ -622,8 +696,9 @@ class InstNormApplyFn(torch.autograd.Function):
     pass alone; the backward is InstNormActFn's."""
 
     @staticmethod
-    def forward(ctx, x, stats, residual, act):
+    def forward(ctx, x, stats, residual, act, token=None):
         lib = _lib.load()
+        ctx.token = token
         x, stats = _req(x, "norm input"), _req(stats, "norm statistics")
         residual = None if residual is None else _req(residual, "norm residual")
         N, H, W, Cn = x.shape
@@ -636,12 +711,14 @@ class InstNormApplyFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dx, dres, _ = InstNormActFn.backward(ctx, dy)
-        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None
+        dx = InstNormActFn.backward(ctx, dy)[0]
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None, None
 
 
 def instnorm_apply(x, stats, act=ACT_RELU, residual=None):
-    return InstNormApplyFn.apply(x, stats, residual, act)
+    token = _norm_token(act)
+    y = InstNormApplyFn.apply(x, stats, residual, act, token)
+    return _tag_norm_output(y, x, stats, token)
 
 
 class BatchNormActFn(torch.autograd.Function):

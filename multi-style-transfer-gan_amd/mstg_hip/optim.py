@@ -75,11 +75,54 @@ class FlatAdam:
                            self.step_count)
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        """torch.optim.Adam's layout (what pretrain.py:210-216 saves and pretrain_resume.py:146-147 loads into optim.Adam): per-parameter
+        ``state[i] = {step, exp_avg, exp_avg_sq}`` sliced out of the flat buffers, ``param_groups`` with parameter indices.  As
+        with torch, a parameter that never received a gradient (both moments identically zero) has no state entry."""
+        g = self.param_groups[0]
+        state = {}
+        if self.step_count > 0:
+            m_all, v_all = self.exp_avg.detach(), self.exp_avg_sq.detach()
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                m, v = m_all[o:o + p.numel()], v_all[o:o + p.numel()]
+                if bool((m != 0).any()) or bool((v != 0).any()):
+                    state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m.view_as(p).clone(),
+                                "exp_avg_sq": v.view_as(p).clone()}
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
 
+    @torch.no_grad()
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups[0].update(sd["param_groups"][0])
+        """Accepts torch.optim.Adam's state_dict (a checkpoint the reference wrote, or this class's own) and the flat layout this
+        class wrote in round 2 ({step, exp_avg, exp_avg_sq, param_groups})."""
+        if "state" not in sd:  # round-2 flat layout
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items() if k != "params"})
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("FlatAdam.load_state_dict: expected one parameter group with "
+                             f"{len(self.params)} parameters, got {[len(g_['params']) for g_ in groups]}")
+        if groups[0].get("weight_decay", 0) or groups[0].get("amsgrad", False) or groups[0].get("maximize", False):
+            raise ValueError("FlatAdam.load_state_dict: weight_decay / amsgrad / maximize are not implemented (the reference uses none)")
+        index_of = {pid: i for i, pid in enumerate(groups[0]["params"])}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for pid, st in sd["state"].items():
+            i = index_of[pid]
+            p, o = self.params[i], self.offsets[i]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam.load_state_dict: state {pid} has shape {tuple(st['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+            self.exp_avg[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam.load_state_dict: parameters at different step counts {sorted(steps)} (one fused step serves all)")
+        self.step_count = steps.pop() if steps else 0
+        self.param_groups[0].update({k: groups[0][k] for k in ("lr", "eps") if k in groups[0]})
+        if "betas" in groups[0]:
+            self.param_groups[0]["betas"] = tuple(groups[0]["betas"])

@@ -119,13 +119,20 @@ class CosineLR:
         return [self.optimizer.param_groups[0]["lr"]]
 
     def state_dict(self):
-        return {"T_max": self.T_max, "eta_min": self.eta_min, "base_lr": self.base_lr, "last_epoch": self.last_epoch}
+        """The keys torch.optim.lr_scheduler.CosineAnnealingLR.state_dict() holds (it is ``__dict__`` minus the optimizer), so that
+        pretrain_resume.py:149-150 can load it into the torch scheduler."""
+        return {"T_max": self.T_max, "eta_min": self.eta_min, "base_lrs": [self.base_lr], "last_epoch": self.last_epoch,
+                "_step_count": self.last_epoch + 1, "_get_lr_called_within_step": False, "_last_lr": self.get_last_lr()}
 
     def load_state_dict(self, sd):
-        self.T_max, self.eta_min, self.base_lr, self.last_epoch = sd["T_max"], sd["eta_min"], sd["base_lr"], sd["last_epoch"]
+        """torch's CosineAnnealingLR state (``base_lrs``) or the round-2 layout of this class (``base_lr``)."""
+        self.T_max, self.eta_min, self.last_epoch = sd["T_max"], sd["eta_min"], int(sd["last_epoch"])
+        self.base_lr = sd["base_lrs"][0] if "base_lrs" in sd else sd["base_lr"]
         if self.last_epoch:
             self.last_epoch -= 1
             self.step()
+        else:
+            self.optimizer.param_groups[0]["lr"] = self.base_lr
 
 
 class PretrainStep:
@@ -149,8 +156,28 @@ class PretrainStep:
         return loss.detach()
 
 
-def train(data_root, save_dir, num_epochs=200, batch_size=1, lr=2e-4, channels=64, datasets=None, log_every=10):
-    """pretrain.py:99-230.  ``datasets`` = (monet_dataset, photo_dataset) overrides the directory-backed ones."""
+def load_checkpoint(path, generator, optimizer=None, scheduler=None, device=None):
+    """pretrain_resume.py:134-157: ``model_state_dict`` (or a bare state dict), then -- when present -- optimizer and scheduler
+    state, start_epoch = checkpoint['epoch'] + 1.  Reads with weights_only=True (nothing in the file is executed)."""
+    ckpt = torch.load(path, map_location=device, weights_only=True)
+    generator.load_state_dict(ckpt["model_state_dict"] if "model_state_dict" in ckpt else ckpt)
+    start_epoch = 0
+    if isinstance(ckpt, dict):
+        if optimizer is not None and "optimizer_state_dict" in ckpt:
+            optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        if scheduler is not None and "scheduler_state_dict" in ckpt:
+            scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        if "epoch" in ckpt:
+            start_epoch = int(ckpt["epoch"]) + 1
+    return start_epoch
+
+
+def train(data_root, save_dir, num_epochs=200, batch_size=1, lr=2e-4, channels=64, datasets=None, log_every=10, resume_path=None,
+          continue_epochs=False, save_every=50):
+    """pretrain.py:99-230, and with ``resume_path`` pretrain_resume.py:134-157.  ``datasets`` = (monet_dataset, photo_dataset)
+    overrides the directory-backed ones.  As in the reference, a resumed run restores model / optimizer / scheduler and reports
+    ``start_epoch`` but its loop still counts from 0 (pretrain_resume.py:166); ``continue_epochs=True`` starts the loop at
+    ``start_epoch`` instead."""
     set_seed()
     if not torch.cuda.is_available():
         raise RuntimeError("pretrain.train (MI355X build) needs a GPU: there is no CPU path")
@@ -163,8 +190,12 @@ def train(data_root, save_dir, num_epochs=200, batch_size=1, lr=2e-4, channels=6
     generator = Generator(channels=channels).to(device)
     step = PretrainStep(generator, lr=lr)
     scheduler = CosineLR(step.optimizer, T_max=num_epochs, eta_min=1e-6)
+    start_epoch = 0
+    if resume_path is not None and os.path.exists(resume_path):
+        start_epoch = load_checkpoint(resume_path, generator, step.optimizer, scheduler, device)
+        print(f"[INFO] resumed from {resume_path}: start_epoch {start_epoch}")
     history = []
-    for epoch in range(num_epochs):
+    for epoch in range(start_epoch if continue_epochs else 0, num_epochs):
         generator.train()
         for name, loader in (("monet", monet_loader), ("photo", photo_loader)):
             running = None
@@ -176,7 +207,7 @@ def train(data_root, save_dir, num_epochs=200, batch_size=1, lr=2e-4, channels=6
                     running = None
             history.append((epoch, name, float(loss)))
         scheduler.step()
-        if (epoch + 1) % 50 == 0:
+        if (epoch + 1) % save_every == 0:
             torch.save({"epoch": epoch,
                         "model_state_dict": {k: v.detach().clone() for k, v in generator.state_dict().items()},
                         "optimizer_state_dict": step.optimizer.state_dict(),

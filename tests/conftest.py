@@ -16,6 +16,48 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# A GPU-clean helper process for tests that must start other programs (the two-rank data-parallel rehearsal): once this session
+# has initialised the GPU it may not exec anything, whatever the order the tests run in (tools/clean_launcher.py).
+_LAUNCHER = None
+
+
+def pytest_sessionstart(session):
+    global _LAUNCHER
+    try:
+        import torch
+        have_gpu = torch.cuda.device_count() >= 1 and not torch.cuda.is_initialized()  # device_count() does not initialise it
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        import subprocess
+        _LAUNCHER = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "clean_launcher.py")], stdin=subprocess.PIPE,
+                                     stdout=subprocess.PIPE, text=True, bufsize=1)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _LAUNCHER
+    if _LAUNCHER is not None:
+        try:
+            _LAUNCHER.stdin.close()
+            _LAUNCHER.wait(timeout=10)
+        except Exception:
+            _LAUNCHER.kill()
+        _LAUNCHER = None
+
+
+def launch_clean(cmd, env=None, cwd=None, timeout=600):
+    """Run ``cmd`` from the GPU-clean helper; returns a dict(returncode, stdout, stderr).  Raises if the helper is missing."""
+    import json
+    if _LAUNCHER is None or _LAUNCHER.poll() is not None:
+        raise RuntimeError("no GPU-clean launcher process (tests/conftest.py starts it at session start when a GPU is present)")
+    _LAUNCHER.stdin.write(json.dumps({"cmd": cmd, "env": env, "cwd": cwd, "timeout": timeout}) + "\n")
+    _LAUNCHER.stdin.flush()
+    line = _LAUNCHER.stdout.readline()
+    if not line:
+        raise RuntimeError("the GPU-clean launcher process died")
+    return json.loads(line)
+
+
 def usable_cpus() -> int:
     """Cores this process may really use (the GPU box shows 256 logical CPUs and grants 16 through its cgroup): torch sizes its
     thread pool by the former, and an oracle run then crawls under 16x oversubscription."""

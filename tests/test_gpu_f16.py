@@ -182,6 +182,30 @@ def test_f16_generator_vs_fp32_path(shape):
     report(f"fp16 vs fp32 {shape[2]}x{shape[3]} out", rel_l2(y16.float(), y32), 2e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 256, 256)])
+def test_f16_generator_with_transformer_block_vs_fp32_path(shape):
+    """What every inference caller of the reference builds (num_transformer_blocks=1: direct_transform.py:35, advanced_transform.py:29,
+    batch_process_images.py:95): the fp16 plan runs the block on the fp32 kernels between down2 and up1.  Same bars as the
+    block-free model (3e-2 at the taps / pre-tanh, 2e-2 on the image), against this build's fp32 path."""
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    m = eg.EnhancedGenerator(channels=16, num_transformer_blocks=1)
+    m.load_state_dict(R.make_state_dict(R.generator_spec_with_blocks(16, 1), 421))
+    m.to(DEV).eval()
+    x = R.make_input(shape, 422).to(DEV)
+    t32, t16 = {}, {}
+    with torch.no_grad():
+        y32 = m.forward_taps(x, t32)
+        m.half_inference()
+        y16 = m.forward_taps(x, t16)
+        y16b = m(x)
+        m.half_inference(False)
+    assert y16.dtype == torch.float16 and torch.isfinite(y16).all() and torch.equal(y16, y16b)
+    for k in ("down2", "up1", "up2", "pre_tanh"):
+        report(f"fp16+block vs fp32 {shape[2]}x{shape[3]} tap {k}", rel_l2(t16[k].float(), t32[k]), 3e-2)
+    report(f"fp16+block vs fp32 {shape[2]}x{shape[3]} out", rel_l2(y16.float(), y32), 2e-2)
+
+
 def test_f16_generator_contract():
     """The reference's callers: eval() + no_grad + strict load_state_dict (direct_transform.py:35-63).  The packed filters follow
     a load_state_dict; autograd-enabled calls keep the fp32 path; bad shapes raise like the reference; other widths raise."""
@@ -206,7 +230,7 @@ def test_f16_generator_contract():
             with pytest.raises(RuntimeError):
                 m(torch.zeros(bad, device=DEV))
         with pytest.raises(RuntimeError, match="channels=16"):
-            eg.EnhancedGenerator(channels=8, num_transformer_blocks=0).to(DEV).half_inference()(torch.zeros((1, 3, 32, 32), device=DEV))
+            eg.EnhancedGenerator(channels=8, num_transformer_blocks=0).to(DEV).half_inference()  # raises at once, not at first use
         y16in = m(x.half())  # an fp16 image is accepted too
     assert torch.equal(y16in, m.half_inference()._half().forward(x.half().float()))
 

@@ -209,3 +209,107 @@ def test_pretrain_and_train_loops_run_and_checkpoints_round_trip(tmp_path):
     assert fresh.load_models(tmp_path / "gan", 2) == 2
     for k, v in model.G_AB.state_dict().items():
         assert torch.equal(v, fresh.G_AB.state_dict()[k]), k
+
+
+def test_optimizer_and_scheduler_state_are_torch_shaped(tmp_path):
+    """pretrain.py:210-216 saves torch.optim.Adam / CosineAnnealingLR state and pretrain_resume.py:146-150 loads it into those
+    classes: FlatAdam / CosineLR must write that layout and read it back, in both directions, and a resumed step must be the step
+    the un-interrupted run would have taken."""
+    import pretrain
+    from mstg_hip.optim import FlatAdam
+    torch.manual_seed(0)
+    shapes = [(8, 3, 4, 4), (8,), (5, 7), (3,)]
+    base = [torch.randn(s) for s in shapes]
+    grads = [[torch.randn(s) for s in shapes] for _ in range(4)]
+    for g_ in grads:
+        g_[3] = None  # a parameter that never receives a gradient (style_encoder at blocks = 0): torch keeps no state for it
+    ours = [torch.nn.Parameter(t.clone().to(DEV)) for t in base]
+    ref = [torch.nn.Parameter(t.clone()) for t in base]
+    fo, to = FlatAdam(ours, lr=2e-4, betas=(0.5, 0.999)), torch.optim.Adam(ref, lr=2e-4, betas=(0.5, 0.999))
+
+    def step_both(k, flat_opt, torch_opt, ps_ref):
+        flat_opt.zero_grad()
+        for p, p_r, g_ in zip(flat_opt.params, ps_ref, grads[k]):
+            p_r.grad = None if g_ is None else g_.clone()
+            if g_ is not None:
+                p.grad.copy_(g_)
+        flat_opt.step()
+        torch_opt.step()
+
+    for k in range(3):
+        step_both(k, fo, to, ref)
+    sd = fo.state_dict()
+    assert set(sd) == {"state", "param_groups"} and set(sd["state"]) == {0, 1, 2} and sd["param_groups"][0]["params"] == [0, 1, 2, 3]
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    torch.save({"optimizer_state_dict": sd}, tmp_path / "o.pth")
+    sd = torch.load(tmp_path / "o.pth", map_location="cpu", weights_only=True)["optimizer_state_dict"]
+    # (a) our state -> torch.optim.Adam on fresh CPU parameters holding our current values
+    ref2 = [torch.nn.Parameter(p.detach().cpu().clone()) for p in ours]
+    to2 = torch.optim.Adam(ref2, lr=1.0)
+    to2.load_state_dict(sd)
+    assert to2.param_groups[0]["lr"] == 2e-4 and tuple(to2.param_groups[0]["betas"]) == (0.5, 0.999)
+    # (b) torch's state -> FlatAdam on fresh GPU parameters
+    ours2 = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    fo2 = FlatAdam(ours2, lr=1.0, betas=(0.9, 0.9))
+    fo2.load_state_dict(to.state_dict())
+    assert fo2.step_count == 3 and fo2.param_groups[0]["lr"] == 2e-4 and fo2.param_groups[0]["betas"] == (0.5, 0.999)
+    # the 4th step from every restored state equals the un-interrupted one
+    step_both(3, fo, to, ref)
+    step_both(3, fo2, to2, ref2)
+    for a, b, c, d in zip(ours, ref, ours2, ref2):
+        assert torch.allclose(a.detach().cpu(), b.detach(), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(c.detach().cpu(), b.detach(), rtol=1e-6, atol=1e-7)
+        assert torch.allclose(d.detach(), b.detach(), rtol=1e-6, atol=1e-7)
+    # round-2 flat layout still loads
+    fo3 = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in ours], lr=1.0)
+    fo3.load_state_dict({"step": 4, "exp_avg": fo.exp_avg.clone(), "exp_avg_sq": fo.exp_avg_sq.clone(), "param_groups": [{"lr": 3e-4}]})
+    assert fo3.step_count == 4 and fo3.param_groups[0]["lr"] == 3e-4
+
+
+def test_pretrain_resume_and_convert_model(tmp_path):
+    """pretrain_resume.py:134-157 on a checkpoint this package wrote, and on one written the way the REFERENCE writes it (torch's own
+    Adam + CosineAnnealingLR state); convert_model.py:12-29 wrapper flattening and the inference callers' load convention."""
+    import convert_model
+    import enhanced_generator as eg
+    import plain_generator
+    import pretrain
+    import pretrain_resume
+    from oracle import restatement as R
+    arrays_a = [_img(90 + 3 * i, 100 + 5 * i, 60 + i) for i in range(2)]
+    ds = (pretrain.MonetPhotoDataset(arrays=arrays_a, device=DEV, img_size=64), pretrain.MonetPhotoDataset(arrays=arrays_a, device=DEV, img_size=64))
+    gen, _ = pretrain.train(None, tmp_path / "a", num_epochs=2, batch_size=2, channels=8, datasets=ds, log_every=1000, save_every=2)
+    path = tmp_path / "a" / "generator_pretrain_epoch_2.pth"
+    g2 = plain_generator.Generator(channels=8).to(DEV)
+    step = pretrain.PretrainStep(g2)
+    sched = pretrain.CosineLR(step.optimizer, T_max=2, eta_min=1e-6)
+    assert pretrain.load_checkpoint(path, g2, step.optimizer, sched, DEV) == 2
+    assert step.optimizer.step_count > 0 and sched.last_epoch == 2
+    for (k, v), (_, v2) in zip(gen.state_dict().items(), g2.state_dict().items()):
+        assert torch.equal(v, v2), k
+    # a checkpoint the way the reference writes it: plain torch modules / optimizer / scheduler on the CPU
+    g_ref = plain_generator.Generator(channels=8)
+    opt = torch.optim.Adam(g_ref.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-6)
+    for p in g_ref.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step()
+    sch.step()
+    torch.save({"epoch": 0, "model_state_dict": g_ref.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                "scheduler_state_dict": sch.state_dict(), "loss": 0}, tmp_path / "ref.pth")
+    gen3, hist = pretrain_resume.train(None, tmp_path / "b", num_epochs=1, batch_size=2, datasets=ds, log_every=1000, channels=8,
+                                       resume_path=tmp_path / "ref.pth", save_every=1)
+    assert len(hist) == 2 and all(np.isfinite(h[2]) for h in hist)
+    # convert_model: wrappers -> bare state dicts; the loading convention of the inference callers
+    sd = R.make_state_dict(R.generator_spec_with_blocks(8, 1), 5)
+    torch.save({"epoch": 20, "G_BA_state_dict": sd}, tmp_path / "G_BA_epoch_20.pth")
+    assert convert_model.convert_model(tmp_path / "G_BA_epoch_20.pth", tmp_path / "flat.pth")
+    flat = torch.load(tmp_path / "flat.pth", map_location="cpu", weights_only=True)
+    assert list(flat) == list(sd) and all(torch.equal(flat[k], sd[k]) for k in sd)
+    assert convert_model.flatten_checkpoint({"epoch": 3, "model_state_dict": {"w": 1}}) == {"w": 1}
+    assert convert_model.flatten_checkpoint({"epoch": 3, "state_dict": {"w": 2}}) == {"w": 2}
+    assert convert_model.flatten_checkpoint({"epoch": 3, "w": 4, "G_x": 5}) == {"w": 4}
+    assert not convert_model.convert_model(tmp_path / "missing.pth", tmp_path / "x.pth")
+    for path_ in (tmp_path / "G_BA_epoch_20.pth", tmp_path / "flat.pth"):
+        m = convert_model.load_generator(path_, device=DEV, direction="BA")
+        assert isinstance(m, eg.EnhancedGenerator) and not m.training and m.initial[0].weight.shape[0] == 8
+        assert torch.equal(m.state_dict()["up2.0.weight"].cpu(), sd["up2.0.weight"])

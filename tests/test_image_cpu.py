@@ -70,3 +70,38 @@ def test_blend_restatements():
     img = _img(120, 200, 9)
     res = IR.process_local_style_ref(lambda x: -x, img, mode="simple", strength=0.5)
     assert res.shape == img.shape and res.dtype == np.uint8
+
+
+def test_cosine_lr_state_is_torch_shaped():
+    """pretrain.py:211-214 / pretrain_resume.py:149-150: the scheduler state travels through torch's CosineAnnealingLR both ways."""
+    import torch
+    import pretrain
+
+    class _Opt:  # what CosineLR needs of an optimizer
+        def __init__(self, lr):
+            self.param_groups = [{"lr": lr}]
+
+    ours = pretrain.CosineLR(_Opt(2e-4), T_max=7, eta_min=1e-6)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=2e-4)
+    ref = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=7, eta_min=1e-6)
+    for _ in range(3):
+        ours.step()
+        opt.step()
+        ref.step()
+    assert abs(ours.get_last_lr()[0] - ref.get_last_lr()[0]) <= 1e-12
+    sd = ours.state_dict()
+    assert {"T_max", "eta_min", "base_lrs", "last_epoch", "_last_lr", "_step_count"} <= set(sd)
+    opt2 = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=2e-4)
+    ref2 = torch.optim.lr_scheduler.CosineAnnealingLR(opt2, T_max=99, eta_min=0.0)
+    ref2.load_state_dict(sd)
+    assert ref2.T_max == 7 and ref2.last_epoch == 3 and abs(ref2.get_last_lr()[0] - ours.get_last_lr()[0]) <= 1e-12
+    ours2 = pretrain.CosineLR(_Opt(1.0), T_max=1)
+    ours2.load_state_dict(ref.state_dict())
+    ours2.step()
+    opt.step()
+    ref.step()
+    assert ours2.last_epoch == 4 and abs(ours2.get_last_lr()[0] - ref.get_last_lr()[0]) <= 1e-12
+    ours3 = pretrain.CosineLR(_Opt(1.0), T_max=1)
+    ours3.load_state_dict({"T_max": 7, "eta_min": 1e-6, "base_lr": 2e-4, "last_epoch": 3})  # the round-2 layout
+    assert abs(ours3.get_last_lr()[0] - ours.get_last_lr()[0]) <= 1e-15
