@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
     for (int f = 0; f < (STATS ? NF : 1); ++f)
 #pragma unroll
         for (int q = 0; q < 4; ++q) ssum[f][q] = ssq[f][q] = 0.f;
+    const int lb = STATS ? xcd_swizzle((int)blockIdx.x, G) : (int)blockIdx.x;  // logical index of this workgroup's tile range (below)
     auto flush_stats = [&](int n_img) {  // between tiles only (the scratch aliases the patch); ends with a barrier
         float* red = reinterpret_cast<float*>(patch);  // [4 waves][2][16 * NF]
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             }
         __syncthreads();
         if (tid < 2 * 16 * NF)
-            a.partial[((size_t)n_img * G + blockIdx.x) * 2 * 16 * NF + tid] = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
+            a.partial[((size_t)n_img * G + lb) * 2 * 16 * NF + tid] = red[tid] + red[2 * 16 * NF + tid] + red[4 * 16 * NF + tid] + red[6 * 16 * NF + tid];
         __syncthreads();
     };
     int cur_n = -1;
@@ -197,9 +198,11 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
     // STATS: a workgroup takes a CONTIGUOUS range of tiles, so that an image is covered by a few workgroups and the statistics
     // finalize reads a few rows per image (with the strided order every workgroup touches every image: a row per pair, a memset and a
     // finalize that cost what the statistics pass they replace costs); otherwise the strided, XCD-contiguous order
+    // ... and the ranges are dealt XCD-aware: workgroups b and b + 8 share an XCD (and its L2), so the logical range index is the
+    // XCD-contiguous renumbering of the block index -- the ranges one L2 serves at a time are then neighbours (shared halo rows)
     const int chunk = STATS ? (total_tiles + G - 1) / G : 0;
-    const int t_end = STATS ? min(total_tiles, ((int)blockIdx.x + 1) * chunk) : total_tiles;
-    auto tile_of = [&](int i) { return STATS ? (int)blockIdx.x * chunk + i : p32_tile(i, blockIdx.x, G); };
+    const int t_end = STATS ? min(total_tiles, (lb + 1) * chunk) : total_tiles;
+    auto tile_of = [&](int i) { return STATS ? lb * chunk + i : p32_tile(i, blockIdx.x, G); };
     int t = tile_of(it);
     if (t < t_end) p32_fetch<NPF>(a, p, t, TH, tid, rel, vmask, R);
     while (t < t_end) {
@@ -245,6 +248,19 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             const int s0 = __builtin_amdgcn_readfirstlane(ci.x), s1 = __builtin_amdgcn_readfirstlane(ci.y);
             const int oyc = __builtin_amdgcn_readfirstlane(ci.z), oxc = __builtin_amdgcn_readfirstlane(ci.w);
             f32x4 acc[RPW][NF];
+            // STATS == 2: the raw tensor at the pixels this segment will store, in flight behind the whole K loop
+            const int mul = up ? 2 : 1;
+            const bool full_tile = gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw && (a.Cout & 15) == 0;
+            const size_t ybyte = ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
+            const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 4u;
+            f32x4 av[STATS == 2 ? RPW : 1][STATS == 2 ? NF : 1];
+            if (STATS == 2 && full_tile && !(a.dbg & 2)) {
+                const char* abase = reinterpret_cast<const char*>(a.aux) + ybyte;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) av[STATS == 2 ? r : 0][STATS == 2 ? f : 0] = *reinterpret_cast<const f32x4*>(abase + r * out_row + out_off0 + 64 * f);
+            }
             auto load_ko = [&](int s) -> unsigned { return reinterpret_cast<const unsigned*>(smem)[s]; };
             auto load_ops = [&](unsigned ko, int s, f32x4 (&bf)[RPW], f32x4 (&af)[NF]) {
 #pragma unroll
@@ -284,27 +300,16 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
             }
             if (s < s1) mma_step(bB, aB, P32False{});
             // ---- epilogue of this class: lane holds output channels 16f + 4g + {0..3} of compute-grid pixel (gy, gx0 + nl) --------
-            const int mul = up ? 2 : 1;
             if (a.dbg & 2) continue;
-            if (gy0 + TH <= a.Gh && gx0 + P32_TW <= a.Gw && (a.Cout & 15) == 0) {
-                const size_t ybyte = ((((size_t)n * a.Ho + gy0 * mul + oyc) * a.Wo + gx0 * mul + oxc) * a.Cout) * 4;
+            if (full_tile) {
                 char* ybase = reinterpret_cast<char*>(a.y) + ybyte;
-                const unsigned out_off0 = (unsigned)(((RPW * wv * mul) * a.Wo + nl * mul) * a.Cout + 4 * g) * 4u;
-                f32x4 av[STATS == 2 ? RPW : 1][STATS == 2 ? NF : 1];
-                if (STATS == 2) {  // all of this wave's f loads in flight before the stores go out
-                    const char* abase = reinterpret_cast<const char*>(a.aux) + ybyte;
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                        for (int f = 0; f < NF; ++f) av[STATS == 2 ? r : 0][STATS == 2 ? f : 0] = *reinterpret_cast<const f32x4*>(abase + r * out_row + out_off0 + 64 * f);
-                }
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
 #pragma unroll
                     for (int f = 0; f < NF; ++f) {
                         if (STATS == 1) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
+                            for (int q = 0; q < 4; ++q) { const float dv = acc[r][f][q] - b4[f][q]; ssum[f][q] += dv; ssq[f][q] += dv * dv; }  // pivot = the channel's bias
                         }
                         *reinterpret_cast<f32x4*>(ybase + r * out_row + out_off0 + 64 * f) = acc[r][f];
                     }
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
                                 const size_t oe = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.Cout + 16 * f + 4 * g;
                                 if (STATS == 1) {
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) { ssum[f][q] += acc[r][f][q]; ssq[f][q] += acc[r][f][q] * acc[r][f][q]; }
+                                    for (int q = 0; q < 4; ++q) { const float dv = acc[r][f][q] - b4[f][q]; ssum[f][q] += dv; ssq[f][q] += dv * dv; }  // pivot = the channel's bias
                                 }
                                 if (STATS == 2) {
                                     const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.aux + oe) - amu[STATS == 2 ? f : 0]) * ars[STATS == 2 ? f : 0];
@@ -359,8 +364,11 @@ __global__ __launch_bounds__(256) void conv_p32_kernel(const P32Args a, const P3
 }
 
 // partial [N][G][2][CP] -> stats [N][C][2] = (mean, rstd); one workgroup per image, double accumulation, fixed order
+// The sums are of (y - bias[c]): the epilogue pivots on the channel's bias (as norm.hip pivots on the first pixel), so that a
+// bias-dominated or near-constant channel (|mean| / std of 100 or more) does not lose its variance to the cancellation in
+// E[y^2] - E[y]^2 while the partials are still fp32; mean = bias + E[y - bias].
 __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int G, int CP,
-                                                                int C, float count, int ntile, int chunk) {
+                                                                int C, float count, int ntile, int chunk, const float* __restrict__ pivot) {
     __shared__ double red[256 * 2];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int per_c = 256 / CP, c = tid % CP, sub = tid / CP;  // CP in {16, 32, 64} -> 16 / 8 / 4 threads share a channel
@@ -377,10 +385,10 @@ __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __r
     __syncthreads();
     if (sub == 0 && c < C) {
         for (int k = 1; k < per_c; ++k) { s1 += red[(k * CP + c) * 2]; s2 += red[(k * CP + c) * 2 + 1]; }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;
+        const double e1 = s1 / count;
+        double var = s2 / count - e1 * e1;
         if (var < 0.0) var = 0.0;
-        stats[((size_t)n * C + c) * 2] = (float)mean;
+        stats[((size_t)n * C + c) * 2] = (float)((double)pivot[c] + e1);
         stats[((size_t)n * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
     }
 }
@@ -1013,7 +1021,7 @@ static int p32_launch_t(P32Args& a, const P32Plan& p, size_t lds, long tiles, hi
     } else if (out_stats) {
         const int ntile = a.tiles_x * a.tiles_y;
         MSTG_LAUNCH(p32_norm_finalize_kernel, dim3(a.N), dim3(256), 0, st, (const float*)a.partial, out_stats, (int)g_, 16 * NF, a.Cout,
-                           (float)((size_t)a.Ho * a.Wo), ntile, (int)((tiles + g_ - 1) / g_));
+                           (float)((size_t)a.Ho * a.Wo), ntile, (int)((tiles + g_ - 1) / g_), a.bias);
         MSTG_CHECK_LAUNCH("p32_norm_finalize_kernel");
     }
     return MSTG_OK;

@@ -124,6 +124,66 @@ def test_conv_epilogue_statistics(tr, N, H, W, Ci, Co):
         assert torch.equal(a_, b_)
 
 
+def test_conv_epilogue_statistics_bias_dominated_channels():
+    """|mean| / std of 100 and more (a large bias on small weights) and a near-constant channel: E[y^2] - E[y]^2 from un-pivoted fp32
+    sums loses the variance there (relative error ~1e-7 mean^2 / var); the epilogue pivots on the channel's bias, so (mean, rstd)
+    hold the same 2e-6 bar against fp64 as everywhere else."""
+    from mstg_hip import ops
+    N, H, W, Ci, Co = 2, 64, 64, 16, 32
+    x = rnd((N, H, W, Ci), 41, 1.0)
+    w = rnd((Co, Ci, 4, 4), 42, 1e-2 * (Ci * 16) ** -0.5)
+    w[5] *= 1e-3                                   # a near-constant channel: std ~1e-5 around its bias
+    b = torch.full((Co,), 30.0)
+    b[1::2] = -7.5
+    t = [v.to(DEV) for v in (x, w, b)]
+    y, stats = ops.conv2d_stats(t[0], t[1], t[2], 4, 2, 1, 1)
+    y64 = y.detach().cpu().double()
+    mean64 = y64.mean(dim=(1, 2))
+    rstd64 = (y64.var(dim=(1, 2), unbiased=False) + 1e-5).rsqrt()
+    assert float((mean64.abs() / y64.std(dim=(1, 2))).min()) > 100
+    report("epilogue stats, bias-dominated: mean", rel_l2(stats[..., 0].cpu().double(), mean64), 2e-6)
+    report("epilogue stats, bias-dominated: rstd", rel_l2(stats[..., 1].cpu().double(), rstd64), 2e-6)
+
+
+@pytest.mark.parametrize("tr,N,H,W,Ci,Co,k", [(0, 3, 40, 36, 16, 32, 4), (1, 2, 32, 32, 32, 16, 4), (0, 2, 64, 64, 32, 32, 1), (0, 1, 48, 80, 64, 64, 1)])
+def test_norm_backward_sums_from_the_consumer_convolution(tr, N, H, W, Ci, Co, k, monkeypatch):
+    """y = conv(ReLU(InstanceNorm(x))): with MSTG_NORM_BSUMS (default) the two reductions of the norm's backward come out of the
+    convolution's input-gradient launch (conv_p32_kernel<..., 2>, mstg_conv2d_dgrad_bsums) and norm_partial_kernel<true> does not
+    run; the input gradient must agree with the statistics-pass path (same arithmetic per element, another summation order) and
+    with torch fp32 on the CPU, and the convolution's own gradients are untouched (bit-identical)."""
+    from mstg_hip import _lib, ops
+    x = rnd((N, H, W, Ci), 51, 1.3) + 0.2
+    w = rnd(((Ci, Co, k, k) if tr else (Co, Ci, k, k)), 52, (Ci * k * k) ** -0.5)
+    b = rnd((Co,), 53, 0.3)
+    stride, pad = (2, 1) if k == 4 else (1, 0)
+    gy_shape = None
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MSTG_NORM_BSUMS", mode)
+        t = [v.to(DEV).requires_grad_(True) for v in (x, w, b)]
+        ops.KernelTimer.start()
+        z = ops.instnorm_act(t[0], ops.ACT_RELU)
+        y = ops.conv2d(z, t[1], t[2], k, stride, pad, 1, transposed=bool(tr))
+        if gy_shape is None:
+            gy_shape = tuple(y.shape)
+        g = torch.autograd.grad((y * rnd(gy_shape, 54).to(DEV)).sum(), t)
+        torch.cuda.synchronize()
+        ops.KernelTimer.stop()
+        names = [nm for nm, _ in ops.KernelTimer.kernels()]
+        outs[mode] = ([v.cpu() for v in g], names)
+    (g1, n1), (g0, n0) = outs["1"], outs["0"]
+    assert any(nm.startswith("norm_partial_kernel<true>") for nm in n0)
+    assert not any(nm.startswith("norm_partial_kernel<true>") for nm in n1), n1
+    assert any("p32_bsum_finalize_kernel" in nm for nm in n1)
+    report(f"bsums dx vs statistics pass T{tr} {Ci}->{Co} k{k}", rel_l2(g1[0], g0[0]), 2e-6)
+    assert torch.equal(g1[1], g0[1]) and torch.equal(g1[2], g0[2])
+    xr, wr, br = (v.clone().requires_grad_(True) for v in (x, w, b))
+    zr = F.relu(F.instance_norm(xr.permute(0, 3, 1, 2)))
+    yr = (F.conv_transpose2d(zr, wr, br, stride=2, padding=1) if tr else F.conv2d(zr, wr, br, stride=stride, padding=pad)).permute(0, 2, 3, 1)
+    gr = torch.autograd.grad((yr * rnd(gy_shape, 54)).sum(), [xr, wr, br])
+    report(f"bsums dx vs torch T{tr} {Ci}->{Co} k{k}", rel_l2(g1[0], gr[0]), 5e-5)
+
+
 @pytest.mark.parametrize("N,H,W,Cn", [(3, 16, 16, 16), (2, 32, 32, 32), (1, 64, 64, 64), (2, 128, 128, 16)])
 def test_ms_fusion_folded_norm_vs_chain(N, H, W, Cn):
     """The concat's IN + ReLU folded into the 1x1 fusion convolution (MSFusionFn: normalise-on-load in conv_p32_kernel and in
@@ -185,7 +245,7 @@ def test_ms_fusion_output_statistics_and_apply(N, H, W, Cn):
         report(f"fusion+stats N{N} {H}x{W} C{Cn} {name} vs chain", rel_l2(a_, b_), 2e-5)
 
 
-@pytest.mark.parametrize("env", ["MSTG_NORM_ATTN=0", "MSTG_NORM_EPILOGUE=0", "MSTG_NORM_FUSION=0", "MSTG_P32=0"])
+@pytest.mark.parametrize("env", ["MSTG_NORM_ATTN=0", "MSTG_NORM_EPILOGUE=0", "MSTG_NORM_FUSION=0", "MSTG_P32=0", "MSTG_NORM_BSUMS=0", "MSTG_NO_PACK_CACHE=1"])
 def test_generator_same_with_every_norm_folding_switched_off(env, monkeypatch):
     """The folded InstanceNorms and the persistent kernels are optimisations of the same arithmetic: the generator's output and all
     parameter gradients with each of them switched off agree with the default path: forward <= 5e-5, gradients <= 1e-3 aggregate (the
