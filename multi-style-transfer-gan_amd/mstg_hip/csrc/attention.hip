@@ -718,6 +718,7 @@ static int fused_blocks(int N, int H, int W) {
 
 // The register-resident kernels of csrc/attention_reg.hip (round 3): the default; MSTG_ATTN_REG=0 selects the LDS-tile kernels above.
 int attn_reg_bwd_blocks(int C);
+int attn_reg_bwd_waves(int C);
 int attn_reg_fwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
                  float* y, int N, int H, int W, hipStream_t st);
 int attn_reg_bwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* dy,
@@ -741,7 +742,7 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
         // workspace was sized for); the nsum rows sit behind the nb-slab region as before
         const int kblk = in_stats ? norm_run_len(H, W) : 1, R = (H / 4) * (W / 4) / kblk, nrun = N * R;
         int nbr = attn_reg_bwd_blocks(C);
-        if (nbr > cdiv(nrun, 4)) nbr = cdiv(nrun, 4);
+        if (nbr > cdiv(nrun, attn_reg_bwd_waves(C))) nbr = cdiv(nrun, attn_reg_bwd_waves(C));
         float* nsum = partial + (size_t)nb * F::SLAB;
         if (int rc = attn_reg_bwd(C, x, in_stats, wqkv, bqkv, wp, dy, out, partial, in_stats ? nsum : nullptr, kblk, nbr, N, H, W, st)) return rc;
         if (in_stats) {

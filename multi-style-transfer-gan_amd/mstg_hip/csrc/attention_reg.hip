@@ -309,17 +309,21 @@ __global__ __launch_bounds__(256, fwd_waves_per_simd<C>()) void attn_reg_fwd_ker
 // ============================================================================================================================
 // wave-private LDS images (floats).  "RC": written L(p|c) with 4-byte stores, read L(c|p) with 16-byte loads (stride C + 8);
 // "CR" / square: written with 16-byte stores, read with 4-byte loads (stride = 4 mod 8): both sides conflict-free or hidden.
-template <int C>
+template <int C, int WAVES>
 struct BwdLds {
     static constexpr int LD_RC = C + 8, LD_CR = C + 4, LD_J = 3 * C + 4;
-    static constexpr int Q = 0, K = Q + 16 * LD_RC, DO = K + 16 * LD_RC, V = DO + 16 * LD_RC, P = V + 16 * LD_CR, DS = P + C * LD_CR,
-                         DQKV = DS + C * LD_CR, END = DQKV + 16 * LD_J;
+    // One wave's images.  P^T's image is dead once dV has read it, so dS^T reuses it; q, k, v and dO are all consumed before dQKV is
+    // written, so dQKV overlays them: 14.6 KB per wave at C = 32 (25.6 without the reuse), 7.2 KB at C = 16.  LDS operations of one
+    // wave execute in order, so a later write never overtakes an earlier read of the bytes it reuses.
+    static constexpr int Q = 0, K = Q + 16 * LD_RC, V = K + 16 * LD_RC, DO = V + 16 * LD_CR, P = DO + 16 * LD_RC, DS = P,
+                         END = P + C * LD_CR, DQKV = 0;
+    static_assert(16 * LD_J <= P, "dQKV overlays the q / k / v / dO images");
     static constexpr int SLAB = 4 * C * C + 4 * C;
-    // the filters, shared by the four waves, in the three layouts the chains read with one conflict-free 16-byte load per
+    // the filters, shared by the workgroup's waves, in the three layouts the chains read with one conflict-free 16-byte load per
     // fragment (strides = 8 mod 16): WQ[j][ci] (forward chain), WT[ci][j] = Wqkv^T (dX), WPT[c][co] = Wp^T (dO)
     static constexpr int LD_WQ = C + 8, LD_WT = 3 * C + 8, LD_WP = C + 8;
-    static constexpr int WQ = 4 * END, WT = WQ + 3 * C * LD_WQ, WPT = WT + C * LD_WT, WG_FLOATS = WPT + C * LD_WP;
-    static_assert(4 * END >= SLAB, "the workgroup's gradient slab is staged in the transpose images");
+    static constexpr int WQ = WAVES * END, WT = WQ + 3 * C * LD_WQ, WPT = WT + C * LD_WT, WG_FLOATS = WPT + C * LD_WP;
+    static_assert(WAVES * END >= SLAB, "the workgroup's gradient slab is staged in the transpose images");
 };
 
 // L(p|c) (one row fragment, NF column fragments) -> LDS image [p][c]
@@ -369,31 +373,33 @@ __device__ __forceinline__ void get_sq(f32x4 (&t)[NF][NF], const float* img, int
 // NORM: x is the RAW tensor in front of the stage's InstanceNorm + ReLU (normalised while loaded), dx is the gradient w.r.t. the
 // normalised, ReLU'd tensor z, and the kernel also emits what that norm's backward needs from a pass over dx: per run of kblk
 // consecutive windows (kblk divides the windows per image) one row nsum[run][2][C] of sum dz [z > 0] and sum dz [z > 0] z.
-template <int C, bool NORM>
-__global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
+// WAVES waves per workgroup share the filters in LDS: 4 at C = 16 (four workgroups per CU), 8 at C = 32 (one workgroup per CU, two
+// waves per SIMD: the second wave covers the LDS round trips and VALU stretches of the first)
+template <int C, bool NORM, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, C == 16 ? 4 : WAVES / 4) void attn_reg_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wp,
     const float* __restrict__ dy, float* __restrict__ dx, float* __restrict__ partial, int N, int H, int W,
     const float* __restrict__ in_stats, float* __restrict__ nsum, int kblk) {
-    constexpr int NF = C / 16;
-    typedef BwdLds<C> S;
+    constexpr int NF = C / 16, NT = 64 * WAVES;
+    typedef BwdLds<C, WAVES> S;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     float* my = sm + wave * S::END;
     const int nwx = W / 4, nwy = H / 4, nwin = N * nwx * nwy, nrun = nwin / kblk;
-    const int wv = uniform(blockIdx.x * 4 + wave), nwv = gridDim.x * 4;
+    const int wv = uniform(blockIdx.x * WAVES + wave), nwv = gridDim.x * WAVES;
     // this wave's runs [r0, r1) = windows [r0 * kblk, r1 * kblk): contiguous, so the walker advances by carries
     const int perr = (nrun + nwv - 1) / nwv, r0 = wv * perr < nrun ? wv * perr : nrun, r1 = r0 + perr < nrun ? r0 + perr : nrun;
     const int w0 = r0 * kblk, w1 = r1 * kblk;
 
     // filters -> LDS once per workgroup (registers are for the gradient accumulators: with the three filter layouts in
     // registers the kernel needed 256 VGPRs + ~170 AGPRs and ~140 accvgpr moves per window)
-    for (int e = threadIdx.x; e < 3 * C * C; e += 256) {
+    for (int e = threadIdx.x; e < 3 * C * C; e += NT) {
         const int j = e / C, ci = e - j * C;
         const float v = wqkv[e];
         sm[S::WQ + j * S::LD_WQ + ci] = v;
         sm[S::WT + ci * S::LD_WT + j] = v;
     }
-    for (int e = threadIdx.x; e < C * C; e += 256) {
+    for (int e = threadIdx.x; e < C * C; e += NT) {
         const int co = e / C, c = e - co * C;
         sm[S::WPT + c * S::LD_WP + co] = wp[e];
     }
@@ -424,9 +430,6 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
     for (int f = 0; f < (NORM ? NF : 1); ++f) ns1[f] = ns2[f] = splat(0.f);
 
     f32x4 xr[NF], dyr[NF];
-    NormQ<C> nq;
-    float pcm[NF], pcr[NF];  // (mean, rstd) of channel 16f + i: the L(p|ci) copy of x
-    int n_stats = -1;
     WinWalk cur, nxt;
     cur.start(w0, nwx, nwy);
     nxt = cur;
@@ -438,20 +441,10 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
         const int n = cur.n, wy = cur.wy, wx = cur.wx;
         const bool run_ends = j + 1 == kblk;
         // ---- operands of this window ------------------------------------------------------------------------------------
-        f32x4 xn[NF], dyt[NF], x_pc[NF], dy_pc[NF];
-        fetch_pc<C>(x_pc, x, H, W, n, wy, wx, i, g);
-        fetch_pc<C>(dy_pc, dy, H, W, n, wy, wx, i, g);
+        f32x4 xn[NF], dyt[NF];
         if (NORM) {
-            if (n != n_stats) {
-                nq.load(in_stats, n, g);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const f32x2 s = *reinterpret_cast<const f32x2*>(in_stats + ((size_t)n * C + 16 * f + i) * 2);
-                    pcm[f] = s[0];
-                    pcr[f] = s[1];
-                }
-                n_stats = n;
-            }
+            NormQ<C> nq;  // (mean, rstd) re-read per window (L1 hits): sixteen registers less across the window than keeping them
+            nq.load(in_stats, n, g);
 #pragma unroll
             for (int h = 0; h < NF; ++h) xn[h] = nq.apply(xr[h], h);
         } else {
@@ -486,6 +479,8 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
 #pragma unroll
                 for (int n1 = 0; n1 < NF; ++n1) o_pc[n1] = mfma16(ch.vt[m][r], ch.pt[m][n1][r], o_pc[n1]);
         // ---- proj backward: dO = dY Wp (L(p|c1)); dWp += dY^T O; dbp += colsum dY ------------------------------------------
+        f32x4 dy_pc[NF];  // the L(p|co) copy of dY (4-byte loads of the lines the 16-byte loads brought in), in flight behind dO
+        fetch_pc<C>(dy_pc, dy, H, W, n, wy, wx, i, g);
         f32x4 dO[NF], wpT[NF][NF];  // wpT[f][n][e] = Wp[16f + 4g + e][16n + i]   L(co|c)
 #pragma unroll
         for (int f = 0; f < NF; ++f)
@@ -532,7 +527,6 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
 #pragma unroll
             for (int m = 0; m < NF; ++m) dSt[m][n1] = ch.pt[m][n1] * (dSt[m][n1] - splat(d));
         }
-        put_sq<NF>(my + S::DS, S::LD_CR, dSt, i, g);   // dS^T -> dS later
         // ---- dV^T[c2][p] = sum_c1 P[c1][c2] dO^T[c1][p] ------------------------------------------------------------------------
         f32x4 dqkv[3 * NF];  // dq | dk | dv in L(j|p)
         {
@@ -548,6 +542,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
 #pragma unroll
                     for (int m = 0; m < NF; ++m) dqkv[2 * NF + m] = mfma16(p12[a][m][r], dOt[a][r], dqkv[2 * NF + m]);
         }
+        put_sq<NF>(my + S::DS, S::LD_CR, dSt, i, g);   // dS^T -> dS later; into P^T's image, which dV has just read
         // ---- q, k in L(c|p); norms again in that orientation (registers + cross-g) ------------------------------------------
         f32x4 qh_cp[NF], kh_cp[NF];
         float iq2, ik2;
@@ -607,6 +602,8 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
         }
         put_cp<3 * NF>(my + S::DQKV, S::LD_J, dqkv, i, g);  // dQKV -> L(p|j) later
         // ---- qkv conv backward: dX^T[ci][p] = sum_j Wqkv[j][ci] dQKV^T[j][p] ---------------------------------------------------
+        f32x4 x_pc[NF];  // the L(p|ci) copy of X for dWqkv, in flight behind the dX chain
+        fetch_pc<C>(x_pc, x, H, W, n, wy, wx, i, g);
         f32x4 dXt[NF];
 #pragma unroll
         for (int cf = 0; cf < NF; ++cf) dXt[cf] = splat(0.f);
@@ -638,9 +635,11 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
         // ---- dWqkv[j][ci] += sum_p dQKV[p][j] X[p][ci]; dbqkv += colsum dQKV ----------------------------------------------------
         if (NORM) {
 #pragma unroll
-            for (int f = 0; f < NF; ++f)
+            for (int f = 0; f < NF; ++f) {
+                const f32x2 st2 = *reinterpret_cast<const f32x2*>(in_stats + ((size_t)n * C + 16 * f + i) * 2);  // (mean, rstd) of channel 16f + i
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x_pc[f][r] = fmaxf((x_pc[f][r] - pcm[f]) * pcr[f], 0.f);
+                for (int r = 0; r < 4; ++r) x_pc[f][r] = fmaxf((x_pc[f][r] - st2[0]) * st2[1], 0.f);
+            }
         }
         wave_lds_fence();
         {
@@ -679,9 +678,9 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
             ++j;
         }
     }
-    // ---- this workgroup's slab = wave 0 + wave 1 + wave 2 + wave 3 (fixed order): dWqkv (3C x C) | dWp (C x C) | dbqkv | dbp ----
+    // ---- this workgroup's slab = wave 0 + wave 1 + ... (fixed order): dWqkv (3C x C) | dWp (C x C) | dbqkv | dbp ----
     __syncthreads();  // every wave is done with its transpose images
-    for (int src = 0; src < 4; ++src) {
+    for (int src = 0; src < WAVES; ++src) {
         if (wave == src) {
             const bool first = src == 0;
 #pragma unroll
@@ -722,7 +721,7 @@ __global__ __launch_bounds__(256, C == 16 ? 2 : 1) void attn_reg_bwd_kernel(
         __syncthreads();
     }
     float* out = partial + (size_t)blockIdx.x * S::SLAB;
-    for (int e = threadIdx.x; e < S::SLAB; e += 256) out[e] = sm[e];
+    for (int e = threadIdx.x; e < S::SLAB; e += NT) out[e] = sm[e];
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
@@ -737,8 +736,12 @@ static int reg_cus() {
     return cus;
 }
 
-// workgroups of the backward (= slabs in its workspace): one per CU at C = 32, two at C = 16
-int attn_reg_bwd_blocks(int C) { return reg_cus() * (C == 16 ? 2 : 1); }
+// waves per workgroup / workgroups per CU of the backward
+constexpr int bwd_waves(int C) { return C == 16 ? 4 : 8; }
+constexpr int bwd_wgs_per_cu(int C) { return C == 16 ? 4 : 1; }
+// most workgroups the backward uses (= slabs in its workspace)
+int attn_reg_bwd_blocks(int C) { return reg_cus() * bwd_wgs_per_cu(C); }
+int attn_reg_bwd_waves(int C) { return bwd_waves(C); }
 
 template <int C>
 static int reg_fwd(const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* bp, float* y,
@@ -757,16 +760,17 @@ static int reg_fwd(const float* x, const float* in_stats, const float* wqkv, con
 template <int C>
 static int reg_bwd(const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* dy, float* dx,
                    float* partial, float* nsum, int kblk, int nb, int N, int H, int W, hipStream_t st) {
-    typedef BwdLds<C> S;
+    constexpr int WAVES = bwd_waves(C);
+    typedef BwdLds<C, WAVES> S;
     const size_t lds = (size_t)S::WG_FLOATS * sizeof(float);
     if (in_stats) {
-        static bool once = (hipFuncSetAttribute((const void*)attn_reg_bwd_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        static bool once = ((void)hipFuncSetAttribute((const void*)attn_reg_bwd_kernel<C, true, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        MSTG_LAUNCH((attn_reg_bwd_kernel<C, true>), dim3(nb), dim3(256), lds, st, x, wqkv, bqkv, wp, dy, dx, partial, N, H, W, in_stats, nsum, kblk);
+        MSTG_LAUNCH((attn_reg_bwd_kernel<C, true, WAVES>), dim3(nb), dim3(64 * WAVES), lds, st, x, wqkv, bqkv, wp, dy, dx, partial, N, H, W, in_stats, nsum, kblk);
     } else {
-        static bool once = (hipFuncSetAttribute((const void*)attn_reg_bwd_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+        static bool once = ((void)hipFuncSetAttribute((const void*)attn_reg_bwd_kernel<C, false, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
         (void)once;
-        MSTG_LAUNCH((attn_reg_bwd_kernel<C, false>), dim3(nb), dim3(256), lds, st, x, wqkv, bqkv, wp, dy, dx, partial, N, H, W, in_stats, nsum, 1);
+        MSTG_LAUNCH((attn_reg_bwd_kernel<C, false, WAVES>), dim3(nb), dim3(64 * WAVES), lds, st, x, wqkv, bqkv, wp, dy, dx, partial, N, H, W, in_stats, nsum, 1);
     }
     MSTG_CHECK_LAUNCH("attn_reg_bwd_kernel");
     return MSTG_OK;
