@@ -21,12 +21,15 @@ prints ONE JSON line.  An "image" is one input image pushed through the step; a 
 domain), so value = 2 * batch * N / step_time there, and batch * N / step_time for the generator-only configs.
 
 Besides the contract fields the line carries
-  roofline     : the kernel symbol with the largest share of GPU time, measured with HIP events around every launch of an
-                 instrumented step that follows the timed region (same stream, same shapes): achieved = sum of algorithmic
-                 FLOPs (or bytes) of its launches / sum of their durations, against the MI355X peak;
+  roofline     : the kernel symbol with the largest share of GPU time among ALL launches of an instrumented step that follows the
+                 timed region (same shapes, one stream).  The library itself brackets every kernel it launches with HIP events on
+                 the launch stream (mstg_prof_*, csrc/runtime.hip), so a call that launches two kernels contributes two rows;
+                 achieved = sum of the ALGORITHMIC FLOPs (or bytes) of that symbol's launches (2 FLOP per multiply-add,
+                 no recompute, no padding; tensors read once, written once) / sum of their durations, against the MI355X peak.
+                 `top` = the five largest symbols the same way, `largest_call` = the largest C-ABI call with all its launches;
   cpu_baseline : the oracle's restatement of the same workload (oracle/restatement.py, validated against the reference in the
-                 build container) timed on this box's host cores on a bounded sample; thread counts {1, 8, 32, all} are swept
-                 and the best is `value` (the 1-thread figure is reported beside it).
+                 build container) timed on this box's host cores: thread counts {1, 8, 32, all} are swept on a small probe, then
+                 one warm-up pass and 3-5 timed passes of the workload at the best count; `value` = their median.
 """
 from __future__ import annotations
 

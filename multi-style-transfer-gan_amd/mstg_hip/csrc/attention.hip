@@ -702,10 +702,18 @@ __global__ __launch_bounds__(256) void nsum_reduce_kernel(const float* __restric
     }
 }
 
-// windows per run of the NORM backward: the largest divisor of the windows per image that is <= 16
-static int norm_run_len(int H, int W) {
+int attn_reg_bwd_blocks(int C);
+int attn_reg_bwd_waves(int C);
+// windows per run of the NORM backward: the largest divisor of the windows per image that is <= 16 -- and small enough that every
+// wave of the backward gets about two runs (a run is the unit of work there: with 16-window runs a 16-image batch at 128 x 128
+// gave half the waves nothing to do)
+static int norm_run_len(int N, int H, int W, int C) {
     const int wpi = (H / 4) * (W / 4);
-    for (int k = 16; k > 1; --k)
+    const long waves = (long)attn_reg_bwd_blocks(C) * attn_reg_bwd_waves(C);
+    long cap = ((long)N * wpi) / (2 * waves);
+    if (cap > 16) cap = 16;
+    if (cap < 1) cap = 1;
+    for (int k = (int)cap; k > 1; --k)
         if (wpi % k == 0) return k;
     return 1;
 }
@@ -717,8 +725,6 @@ static int fused_blocks(int N, int H, int W) {
 }
 
 // The register-resident kernels of csrc/attention_reg.hip (round 3): the default; MSTG_ATTN_REG=0 selects the LDS-tile kernels above.
-int attn_reg_bwd_blocks(int C);
-int attn_reg_bwd_waves(int C);
 int attn_reg_fwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
                  float* y, int N, int H, int W, hipStream_t st);
 int attn_reg_bwd(int C, const float* x, const float* in_stats, const float* wqkv, const float* bqkv, const float* wp, const float* dy,
@@ -740,7 +746,7 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
         if (!bwd) return attn_reg_fwd(C, x, in_stats, wqkv, bqkv, wp, bp, out, N, H, W, st);
         // slabs: one per workgroup of four waves, never more workgroups than runs / 4 (and so never more than the nb slabs the
         // workspace was sized for); the nsum rows sit behind the nb-slab region as before
-        const int kblk = in_stats ? norm_run_len(H, W) : 1, R = (H / 4) * (W / 4) / kblk, nrun = N * R;
+        const int kblk = in_stats ? norm_run_len(N, H, W, C) : 1, R = (H / 4) * (W / 4) / kblk, nrun = N * R;
         int nbr = attn_reg_bwd_blocks(C);
         if (nbr > cdiv(nrun, attn_reg_bwd_waves(C))) nbr = cdiv(nrun, attn_reg_bwd_waves(C));
         float* nsum = partial + (size_t)nb * F::SLAB;
@@ -765,7 +771,7 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
     }
     if (in_stats) {
         float* nsum = partial + (size_t)nb * F::SLAB;
-        const int kblk = norm_run_len(H, W), R = (H / 4) * (W / 4) / kblk;
+        const int kblk = norm_run_len(N, H, W, C), R = (H / 4) * (W / 4) / kblk;
         MSTG_LAUNCH((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
                            out, partial, N, H, W, in_stats, nsum, kblk);
         MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel<norm>");
@@ -1370,7 +1376,7 @@ extern "C" int mstg_window_attn_norm_sums_split(void) { return NSUM_SPLIT; }
 extern "C" size_t mstg_window_attn_norm_bwd_workspace_bytes(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32)) return 0;
     const size_t nb = (size_t)fused_blocks(N, H, W);
-    return (nb * (4 * C * C + 4 * C) + (size_t)N * ((H / 4) * (W / 4) / norm_run_len(H, W)) * 2 * C) * sizeof(float);
+    return (nb * (4 * C * C + 4 * C) + (size_t)N * ((H / 4) * (W / 4) / norm_run_len(N, H, W, C)) * 2 * C) * sizeof(float);
 }
 
 extern "C" int mstg_window_attn_norm_bwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv,

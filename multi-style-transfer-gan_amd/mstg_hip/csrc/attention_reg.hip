@@ -25,6 +25,7 @@
 // fixed order, so the second-stage reduce reads 1/16 of what the one-wave kernels produced.  tools/sim_attn_layout.py is the
 // lane-level model this data flow was checked with.
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstg {
 
@@ -374,7 +375,8 @@ __device__ __forceinline__ void get_sq(f32x4 (&t)[NF][NF], const float* img, int
 // normalised, ReLU'd tensor z, and the kernel also emits what that norm's backward needs from a pass over dx: per run of kblk
 // consecutive windows (kblk divides the windows per image) one row nsum[run][2][C] of sum dz [z > 0] and sum dz [z > 0] z.
 // WAVES waves per workgroup share the filters in LDS: 4 at C = 16 (four workgroups per CU), 8 at C = 32 (one workgroup per CU, two
-// waves per SIMD: the second wave covers the LDS round trips and VALU stretches of the first)
+// waves per SIMD).  Measured: the matrix pipe is 63 % busy either way (one or two waves per SIMD, with or without starting the
+// upper four waves half a window late) -- the chain's MFMA -> VALU -> MFMA dependencies, not latency, set the pace.
 template <int C, bool NORM, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, C == 16 ? 4 : WAVES / 4) void attn_reg_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wp,

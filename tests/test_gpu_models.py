@@ -423,7 +423,7 @@ def test_train_step_gradient_distance_distribution():
     gradients -- and then, from that same state, (a) the oracle in fp32 on the host and (b) the HIP step; the sample is the
     aggregate relative L2 distance of the generator gradients from the fp64 ones (enhanced_train.py:59-131).
 
-    Assertions (the discriminator gradients have no flip noise: plain 3x bar):
+    Assertions (generator gradients; the discriminator gradients are held to the same floor / median / 90th-percentile statistics):
       * systematic error: a small systematic backward error would put a FLOOR under the HIP distances that a correct fp32
         implementation's well-conditioned draws do not have (the oracle-fp32's 10th percentile is ~2e-4: no mask flips there).
         The third-smallest of the 96 HIP samples must be <= max(3e-4, 1.5 x the oracle-fp32's third-smallest): a pin three times
@@ -544,9 +544,19 @@ def test_train_step_gradient_distance_distribution():
             ratio, allow = q(hip, pct) / q(f32, pct), max(1.25, allowance(hip, f32, pct, rng))
             print(f"  [parity]     p{pct} ratio {ratio:.2f} (bar 1.25; sampling allowance at this n {allow:.2f})")
             assert ratio <= allow, (tag, pct, ratio, allow)
+    # the discriminator gradients: no ReLU masks of their own to flip at these sizes (LeakyReLU's two slopes, a 16x16 bottleneck),
+    # but the fakes they are evaluated on come out of the generators' fp32 forwards, so a rare sample still moves: same statistics
     dh, d3 = [v for _, v in dist[("d", "hip")]], [v for _, v in dist[("d", "f32")]]
-    print(f"  [parity] d-gradient distance from fp64: max HIP {max(dh):.2e} / oracle-fp32 {max(d3):.2e}")
-    assert max(dh) <= max(1e-4, 3.0 * max(d3))
+    line = "  [parity] d-gradient distance from fp64 (n=%d):" % len(dh)
+    for pct in (10, 50, 90):
+        line += f"  p{pct} HIP {q(dh, pct):.2e} / oracle-fp32 {q(d3, pct):.2e}"
+    print(line + f"   largest three HIP {sorted(dh)[-3:]}  oracle-fp32 {sorted(d3)[-3:]}")
+    for pct in (50, 90):
+        ratio, allow = q(dh, pct) / q(d3, pct), max(1.25, allowance(dh, d3, pct, rng))
+        print(f"  [parity]     d p{pct} ratio {ratio:.2f} (bar 1.25; sampling allowance at this n {allow:.2f})")
+        assert ratio <= allow, ("d", pct, ratio, allow)
+    assert sorted(dh)[2] <= max(3e-5, 1.5 * sorted(d3)[2]), ("floor under the HIP d-distances", sorted(dh)[:3], sorted(d3)[:3])
+    assert max(dh) <= 2e-2  # sanity: a flipped sample, not a broken one
 
 
 def test_train_step_gradients_vs_oracle():
