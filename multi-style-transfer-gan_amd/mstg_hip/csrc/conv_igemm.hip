@@ -882,6 +882,16 @@ static int plan_igemm(IGemmArgs& a, IGemmPlan& p) {
     else p.V = 1;  // any channel count: 4-channel k-slots, the tail quad zero-filled
     p.src = a.x_nchw ? 2 : ((((a.x_ctot | a.x_coff | a.Cr) & 3) == 0) ? 0 : 1);
     p.nfw = a.Co <= 16 ? 1 : (a.Co <= 32 ? 2 : 4);
+    // Deep-channel layers on small maps (the discriminator's 32x32 / 16x16 tail: 64 -> 128 k4 s2, 128 -> 128 3x3) make ~128 workgroups
+    // of 64 output channels -- half the chip's SIMDs get nothing.  Narrower workgroups (32 / 16 output channels) re-stage the (L2-resident)
+    // patch more often but fill the machine: halve the fragment count until there are >= 512 workgroups.  MSTG_NFW_ADAPT=0 keeps 64.
+    {
+        const char* e = env_get(ENV_NFW_ADAPT);
+        if (!(e && e[0] == '0') && !a.dpack && a.Cr >= 64) {
+            const long per = (long)a.N * a.tiles_x * a.tiles_y * (a.phase ? 4 : 1);
+            while (p.nfw > 1 && per * cdiv(a.Co, 16 * p.nfw) < 512) p.nfw >>= 1;
+        }
+    }
     p.CK = 4 * p.V;
     p.CKP = p.V == 4 ? ckp_of<4>() : (p.V == 2 ? 12 : 4);
     const int ckp_heavy = p.V == 4 ? ckp_heavy_of<4>() : p.CKP;
@@ -1202,7 +1212,9 @@ extern "C" int mstg_conv2d_dgrad_bsums_supported(const mstg_conv_desc* d) {
     if (check_desc(d)) return 0;
     IGemmArgs a{};
     if (fill_dgrad_args(d, a)) return 0;
-    return p32_generic(a) && a.Co != 1 && !d->accumulate && d->x_ctot == d->Cin && d->x_coff == 0 ? 1 : 0;
+    if (!(p32_generic(a) && a.Co != 1 && !d->accumulate && d->x_ctot == d->Cin && d->x_coff == 0)) return 0;
+    const char* e = env_get(ENV_BSUMS_ALL);  // MSTG_BSUMS_ALL=1: wherever the kernel can, not only where it pays (tests, A/B)
+    return (e && e[0] == '1') || p32_bsums_pays(a) ? 1 : 0;
 }
 
 extern "C" size_t mstg_conv2d_dgrad_bsums_workspace_bytes(const mstg_conv_desc* d) {

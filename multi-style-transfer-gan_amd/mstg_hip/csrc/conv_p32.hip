@@ -1046,6 +1046,15 @@ int launch_p32(const IGemmArgs& g, void* workspace, size_t workspace_bytes, hipS
 bool p32_generic(const IGemmArgs& g) {
     return p32_eligible(g) && !co1_eligible(g) && !p32i_eligible(g) && !p32d_eligible(g) && !g.x_nchw && !g.y_nchw;
 }
+// Where the backward-sums epilogue is worth its price.  Measured per layer (profiles/r03_bench_b32_256_kernel_table.txt): the epilogue
+// costs the launch 7-30 % where the output has <= 32 channels and the patch <= 8 prefetch registers (then it is cheaper than the
+// two-read statistics pass it replaces: 1x1 fusion convolutions, the 16 <-> 32 channel 4x4 layers), but 45-55 % on the 64-channel /
+// 12-register variants, whose 256 VGPRs it fills -- more than norm_partial_kernel<true> takes on their (small) tensors.
+bool p32_bsums_pays(const IGemmArgs& g) {
+    P32Plan p;
+    if (!p32_generic(g) || p32_plan(g, p)) return false;
+    return g.Co <= 32 && p.npf <= 8;
+}
 
 static int launch_p32_full(const IGemmArgs& g, const float* in_stats, float* out_stats, const float* aux, const float* aux_stats,
                            void* workspace, size_t workspace_bytes, hipStream_t st);

@@ -152,6 +152,8 @@ def test_norm_backward_sums_from_the_consumer_convolution(tr, N, H, W, Ci, Co, k
     run; the input gradient must agree with the statistics-pass path (same arithmetic per element, another summation order) and
     with torch fp32 on the CPU, and the convolution's own gradients are untouched (bit-identical)."""
     from mstg_hip import _lib, ops
+    monkeypatch.setenv("MSTG_BSUMS_ALL", "1")  # also the variants the planner leaves to the statistics pass because it is cheaper there
+    ops.refresh_env()
     x = rnd((N, H, W, Ci), 51, 1.3) + 0.2
     w = rnd(((Ci, Co, k, k) if tr else (Co, Ci, k, k)), 52, (Ci * k * k) ** -0.5)
     b = rnd((Co,), 53, 0.3)
