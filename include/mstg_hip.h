@@ -168,6 +168,13 @@ int mstg_window_attn_core_fwd(const float* qkv, float* o, int N, int H, int W, i
 /* dqkv from d_o; the attention matrix is recomputed from qkv, nothing but qkv is saved by the forward */
 int mstg_window_attn_core_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C, void* stream);
 
+/* The same core for any window size (enhanced_generator.py:7: the constructor default is window_size=8; every caller passes 4,
+ * which the entry points above serve): qkv NHWC (N,H,W,3C) -> o NHWC (N,H,W,C), one workgroup per ws x ws window, plain fp32 loops.
+ * Supported while a window's q|k|v (+ dO, dS in the backward) fits one CU's LDS (mstg_window_attn_ws_supported). */
+int mstg_window_attn_ws_supported(int C, int ws);
+int mstg_window_attn_ws_fwd(const float* qkv, float* o, int N, int H, int W, int C, int ws, void* stream);
+int mstg_window_attn_ws_bwd(const float* qkv, const float* d_o, float* dqkv, int N, int H, int W, int C, int ws, void* stream);
+
 /* Fully fused LocalAttention for C = 16 and 32 (enhanced_generator.py:13-47 in one kernel per direction): the qkv and proj
  * 1x1 convolutions (:28, :36) and the window attention between them; x is read once, y written once.  wqkv (3C,C) and
  * wproj (C,C) are the 1x1 conv weights exactly as stored (OIHW with 1x1 taps).  The backward returns dx and ONE flat

@@ -45,8 +45,11 @@ class LocalAttention(nn.Module):
         H, W = x.shape[1], x.shape[2]
         if H % ws or W % ws:  # the reference's padding branch is broken and raises RuntimeError from .view (:15-23)
             raise RuntimeError(f"LocalAttention: H and W must be multiples of window_size={ws}, got {H}x{W}")
-        if ws != 4:
-            raise RuntimeError("LocalAttention: the HIP kernel implements window_size=4 (the only value the reference uses)")
+        if ws != 4:  # the constructor default (8) and any other size: qkv conv -> general-window core -> proj conv
+            if not ops._lib.load().mstg_window_attn_ws_supported(int(x.shape[3]), int(ws)):
+                raise RuntimeError(f"LocalAttention: window_size={ws} with {x.shape[3]} channels does not fit the general-window kernel "
+                                   f"(a whole window is kept on chip); the reference's callers all use window_size=4")
+            return self.proj(ops.WindowAttnCoreWsFn.apply(self.qkv(x, nhwc=True), ws), nhwc=True)
         if ops.fused_attention_supported(x.shape[3]) and os.environ.get("MSTG_ATTN_UNFUSED") != "1":
             # qkv conv + window attention + proj conv in one kernel: x read once, y written once
             return ops.LocalAttentionFusedFn.apply(x, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias)

@@ -56,6 +56,9 @@ SIGNATURES = {
     "mstg_norm_act_bwd": (_i, [_fp, _fp, _fp, _fp, _i, _i, _i, _i, _i, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_window_attn_core_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_core_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _vp]),
+    "mstg_window_attn_ws_supported": (_i, [_i, _i]),
+    "mstg_window_attn_ws_fwd": (_i, [_fp, _fp, _i, _i, _i, _i, _i, _vp]),
+    "mstg_window_attn_ws_bwd": (_i, [_fp, _fp, _fp, _i, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_fused_supported": (_i, [_i]),
     "mstg_window_attn_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -792,6 +792,33 @@ class WindowAttnCoreFn(torch.autograd.Function):
         return dqkv
 
 
+class WindowAttnCoreWsFn(torch.autograd.Function):
+    """The attention core for window sizes other than 4 (mstg_window_attn_ws_*): qkv NHWC (N,H,W,3C) -> o NHWC (N,H,W,C)."""
+
+    @staticmethod
+    def forward(ctx, qkv, ws):
+        qkv = _req(qkv, "qkv")
+        N, H, W, C3 = qkv.shape
+        Cn = C3 // 3
+        o = torch.empty((N, H, W, Cn), dtype=torch.float32, device=qkv.device)
+        _timed("attn_ws_fwd_kernel", 4 * Cn * Cn * N * H * W, 4 * 4 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_ws_fwd(_p(qkv), _p(o), N, H, W, Cn, int(ws), _stream()), "mstg_window_attn_ws_fwd"))
+        ctx.ws = int(ws)
+        ctx.save_for_backward(qkv)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        do = _req(do, "attention grad_output")
+        N, H, W, C3 = qkv.shape
+        Cn = C3 // 3
+        dqkv = torch.empty_like(qkv)
+        _timed("attn_ws_bwd_kernel", 8 * Cn * Cn * N * H * W, 4 * 7 * Cn * N * H * W, lambda: _lib.check(
+            _lib.load().mstg_window_attn_ws_bwd(_p(qkv), _p(do), _p(dqkv), N, H, W, Cn, ctx.ws, _stream()), "mstg_window_attn_ws_bwd"))
+        return dqkv, None
+
+
 class LocalAttentionFusedFn(torch.autograd.Function):
     """Whole LocalAttention (qkv 1x1 conv -> window attention -> proj 1x1 conv) in one kernel per direction, C = 16 / 32.
     x, y: NHWC (N,H,W,C); wqkv (3C,C,1,1), wproj (C,C,1,1) as stored by the reference."""

@@ -365,6 +365,39 @@ def test_local_attention_golden(gold_dir, tag):
         report(f"LocalAttention[{tag}] d{k} vs reference", rel_l2(gr, torch.from_numpy(g[f"attn_{tag}_d_{k}"])), 1e-4)
 
 
+@pytest.mark.parametrize("ch,ws,shape", [(16, 8, (2, 16, 16, 24)), (32, 8, (1, 32, 8, 16)), (8, 2, (2, 8, 6, 10)), (64, 8, (1, 64, 16, 8)),
+                                         (16, 16, (1, 16, 16, 32))])
+def test_local_attention_other_window_sizes(ch, ws, shape):
+    """LocalAttention with a window size other than 4 -- the constructor default is 8 (enhanced_generator.py:7), no caller uses it --
+    through the general-window core (csrc/attention_ws.hip) against the oracle's local_attention(ws): forward and every gradient;
+    H, W not multiples of the window raise like the reference's .view does; what does not fit a CU's LDS raises."""
+    import enhanced_generator as eg
+    from oracle import restatement as R
+    spec = [("qkv.weight", (3 * ch, ch, 1, 1)), ("qkv.bias", (3 * ch,)), ("proj.weight", (ch, ch, 1, 1)), ("proj.bias", (ch,))]
+    sd = R.make_state_dict(spec, 300 + ch + ws)
+    m = eg.LocalAttention(ch) if ws == 8 else eg.LocalAttention(ch, window_size=ws)
+    assert m.window_size == ws
+    m.load_state_dict(sd)
+    m.to(DEV)
+    x = R.make_input(shape, 301 + ch)
+    xg = x.to(DEV).requires_grad_(True)
+    y = m(xg)
+    gy = R.make_input(tuple(y.shape), 302)
+    grads = torch.autograd.grad((y * gy.to(DEV)).sum(), [xg] + list(m.parameters()))
+    sdr = {"p." + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = R.local_attention(xr, sdr, "p", ws)
+    gr = torch.autograd.grad((yr * gy).sum(), [xr] + [sdr["p." + k] for k, _ in m.named_parameters()])
+    report(f"LocalAttention ws={ws} C={ch} y", rel_l2(y, yr), 2e-5)
+    for name, a_, b_ in zip(["dx"] + [k for k, _ in m.named_parameters()], grads, gr):
+        report(f"LocalAttention ws={ws} C={ch} d {name}", rel_l2(a_, b_), 1e-4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros((1, ch, ws + 1, ws), device=DEV))
+    if ws == 16:
+        with pytest.raises(RuntimeError, match="does not fit"):
+            eg.LocalAttention(256, window_size=16).to(DEV)(torch.zeros((1, 256, 16, 16), device=DEV))
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_multi_scale_block_golden(gold_dir, tag):
     import enhanced_generator as eg
