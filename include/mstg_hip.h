@@ -187,6 +187,16 @@ int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, c
  * normalised tensor never exists in memory.  The backward also returns norm_sums[n][S][2][C], S = mstg_window_attn_norm_sums_split():
  * rows adding up to the per (image, channel) sums of dz * [z > 0] and dz * [z > 0] * z for mstg_norm_bwd_apply (the norm backward's
  * reduction pass, done in this kernel's epilogue). */
+/* mstg_window_attn_bwd / mstg_window_attn_norm_bwd with the four parameter gradients written -- or, accumulate != 0, added -- straight
+ * into the caller's gradient tensors (dwqkv (3C,C), dbqkv (3C), dwproj (C,C), dbproj (C)) by the fixed-order slab reduce, instead of
+ * into one flat vector: the caller's framework then launches no per-parameter accumulation kernels. */
+int mstg_window_attn_bwd_direct(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj, const float* dy,
+                                float* dx, float* dwqkv, float* dbqkv, float* dwproj, float* dbproj, int accumulate, int N, int H, int W, int C,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int mstg_window_attn_norm_bwd_direct(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv, const float* wproj,
+                                     const float* bproj, const float* dy, float* dz, float* dwqkv, float* dbqkv, float* dwproj,
+                                     float* dbproj, int accumulate, float* norm_sums, int N, int H, int W, int C, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 int mstg_window_attn_norm_sums_split(void);
 int mstg_window_attn_norm_fwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv, const float* wproj,
                               const float* bproj, float* y, int N, int H, int W, int C, void* stream);
@@ -215,6 +225,11 @@ int mstg_loss_mean_bwd(const float* a, const float* b, float bconst, size_t n, i
                        float* da, float* db, void* stream);
 /* y = a + b, n floats (residual connections; 16-byte aligned pointers) */
 int mstg_add(const float* a, const float* b, float* y, size_t n, void* stream);
+/* out[j] = sum_i weights[j * n + i] * terms[i][0] for 1..8 scalar loss terms and 1..6 outputs (terms: HOST array of device pointers,
+ * weights: host matrix, row 0 = the differentiable total), and the backward of output 0, dterms[i] = g[0] * weights[i]: the weighted
+ * loss sums of enhanced_train.py:72-81, 95-131 (total + the reported components) in one launch each way */
+int mstg_weighted_sum_fwd(const float* const* terms, const float* weights, int n, int nout, float* out, void* stream);
+int mstg_weighted_sum_bwd(const float* g, const float* weights, int n, float* dterms, void* stream);
 /* masked-image pre-training loss (pretrain.py:160-162): out[0] = mean(|a * (1 - m) - b * (1 - m)|) and da = gscale[0] * d/da;
  * a, b, m same shape (m = the 0/1 mask of MonetPhotoDataset).  Workspace as for mstg_loss_mean_fwd. */
 int mstg_masked_l1_mean_fwd(const float* a, const float* b, const float* m, size_t n, float* out, void* workspace,

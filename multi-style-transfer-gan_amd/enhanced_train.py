@@ -207,9 +207,8 @@ class EnhancedCycleGAN:
             fake_B_score, _ = D_B(fake_B.detach())
             dB_real, dB_fake = ops.mse_to_const(real_B_score, 1.0), ops.mse_to_const(fake_B_score, 0.0)
         join(dA_real, dA_fake, dB_real, dB_fake)
-        d_real_loss = (dA_real + dB_real) * 0.5
-        d_fake_loss = (dA_fake + dB_fake) * 0.5
-        d_loss = d_real_loss + d_fake_loss
+        # (dA_real + dB_real) * 0.5 + (dA_fake + dB_fake) * 0.5 (:72-81) as one weighted sum (one launch each way)
+        d_loss = ops.weighted_sum((dA_real, dB_real, dA_fake, dB_fake), (0.5, 0.5, 0.5, 0.5))
         d_loss.backward()
         # The discriminator exchange + update (one all-reduce over the flat gradient buffer, one fused Adam launch) runs on a
         # stream of its own: in the generator phase only the discriminator forwards depend on it, so the two cycle reconstructions
@@ -234,7 +233,7 @@ class EnhancedCycleGAN:
                 with on(sA):
                     idt_B = G_AB(real_B)
                 join(idt_A, idt_B)
-            identity_loss = (ops.l1_loss(idt_A, real_A) + ops.l1_loss(idt_B, real_B)) * self.lambda_identity
+            idA_l, idB_l = ops.l1_loss(idt_A, real_A), ops.l1_loss(idt_B, real_B)
             # The reference runs D on the fakes a second time for the structure heads (:110-113).  Outputs are the
             # same function of the same inputs except for the spectral-norm power iteration that every train-mode
             # forward performs, so the call count per D is kept at the reference's 5 per step, in the reference's order.
@@ -273,10 +272,13 @@ class EnhancedCycleGAN:
                 _, fake_A_struct = D_A(fake_A)
                 sA_l = ops.l1_loss(real_A_struct, fake_A_struct)
             join(gA, gB, cA, cB, sA_l, sB_l)
-            g_loss = gA + gB
-            cycle_loss = (cA + cB) * self.lambda_cycle
-            structure_loss = (sA_l + sB_l) * self.lambda_structure
-            total_g_loss = g_loss + cycle_loss + identity_loss + structure_loss
+            # g + cycle * lambda + identity * lambda + structure * lambda (:95-118): the total as ONE weighted sum over the eight terms
+            # (one launch forward, one backward); the four reported components come out of the same launch, without a graph
+            lc, li, ls = self.lambda_cycle, self.lambda_identity, self.lambda_structure
+            total_g_loss, parts = ops.weighted_sum((gA, gB, cA, cB, idA_l, idB_l, sA_l, sB_l), (1.0, 1.0, lc, lc, li, li, ls, ls),
+                                                   report=((1.0, 1.0, 0, 0, 0, 0, 0, 0), (0, 0, lc, lc, 0, 0, 0, 0), (0, 0, 0, 0, li, li, 0, 0),
+                                                           (0, 0, 0, 0, 0, 0, ls, ls)))
+            g_loss, cycle_loss, identity_loss, structure_loss = parts[0], parts[1], parts[2], parts[3]
             style = None
             if self.style_loss is not None:
                 style = self.style_loss(fake_A) * self.lambda_style

@@ -74,6 +74,8 @@ SIGNATURES = {
     "mstg_norm_stats": (_i, [_fp, _fp, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_norm_bwd_apply": (_i, [_fp, _fp, _fp, _fp, _i, _fp, _i, _i, _i, _i, _vp]),
     "mstg_window_attn_norm_sums_split": (_i, []),
+    "mstg_window_attn_bwd_direct": (_i, [_fp] * 11 + [_i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_window_attn_norm_bwd_direct": (_i, [_fp] * 12 + [_i, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_window_attn_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "mstg_act_fwd": (_i, [_fp, _fp, _sz, _i, _vp]),
     "mstg_act_bwd": (_i, [_fp, _fp, _fp, _sz, _i, _vp]),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "mstg_f16_attn_pack": (_i, [_fp, _fp, _fp, _fp, _i, _vp, _sz, _vp]),
     "mstg_f16_attn_fwd": (_i, [_vp, _fp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mstg_add": (_i, [_fp, _fp, _fp, _sz, _vp]),
+    "mstg_weighted_sum_fwd": (_i, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), _i, _i, _fp, _vp]),
+    "mstg_weighted_sum_bwd": (_i, [_fp, C.POINTER(C.c_float), _i, _fp, _vp]),
     "mstg_masked_l1_mean_fwd": (_i, [_fp, _fp, _fp, _sz, _fp, _vp, _sz, _vp]),
     "mstg_masked_l1_mean_bwd": (_i, [_fp, _fp, _fp, _sz, _fp, _fp, _vp]),
     "mstg_clip_grad_norm": (_i, [_fp, _sz, _f, _fp, _vp, _sz, _vp]),

@@ -667,8 +667,18 @@ __global__ __launch_bounds__(64) void attn_fused_bwd_kernel(const float* __restr
     }
 }
 
+// Where the fused attention's reduced parameter gradients go: the flat vector `out` (dWqkv | dWp | dbqkv | dbp), or -- `dst.p[0]` set --
+// the four parameter-gradient tensors themselves, optionally accumulating (the *_direct entry points: autograd then has nothing to
+// add, four launches less per attention and backward pass).
+struct AttnGradDst {
+    float* p[4];  // dWqkv (3C x C), dWp (C x C), dbqkv (3C), dbp (C)
+    int accumulate;
+};
+thread_local AttnGradDst t_attn_dst = {{nullptr, nullptr, nullptr, nullptr}, 0};
+
 // out[e] = sum_s partial[s][e], fixed order; 16 outputs x 16 strided rows per workgroup
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, int n) {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out, int S, int n,
+                                                          AttnGradDst dst, int C) {
     __shared__ float sh[16][17];
     const int e = threadIdx.x & 15, row = threadIdx.x >> 4, idx = blockIdx.x * 16 + e;
     float sum = 0.f;
@@ -680,7 +690,14 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
         float r = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) r += sh[k][e];
-        out[idx] = r;
+        if (!dst.p[0]) {
+            out[idx] = r;
+        } else {
+            const int c2 = C * C;
+            float* o = idx < 3 * c2 ? dst.p[0] + idx : (idx < 4 * c2 ? dst.p[1] + (idx - 3 * c2) : (idx < 4 * c2 + 3 * C ? dst.p[2] + (idx - 4 * c2)
+                                                                                                                      : dst.p[3] + (idx - 4 * c2 - 3 * C)));
+            *o = dst.accumulate ? *o + r : r;
+        }
     }
 }
 
@@ -755,7 +772,7 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
             MSTG_LAUNCH(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
             MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
         }
-        MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nbr, F::SLAB);
+        MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nbr, F::SLAB, t_attn_dst, C);
         MSTG_CHECK_LAUNCH("slab_reduce_kernel");
         return MSTG_OK;
     }
@@ -782,7 +799,7 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
                            out, partial, N, H, W, in_stats, (float*)nullptr, 1);
         MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
     }
-    MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB);
+    MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB, t_attn_dst, C);
     MSTG_CHECK_LAUNCH("slab_reduce_kernel");
     return MSTG_OK;
 }
@@ -1384,7 +1401,7 @@ extern "C" int mstg_window_attn_norm_bwd(const float* x_raw, const float* in_sta
                                          float* norm_sums, int N, int H, int W, int C, void* workspace, size_t workspace_bytes,
                                          void* stream) {
     if (int rc = attn_check(N, H, W, C)) return rc;
-    if (!x_raw || !in_stats || !wqkv || !bqkv || !wproj || !bproj || !dy || !dz || !dparams || !norm_sums || !workspace)
+    if (!x_raw || !in_stats || !wqkv || !bqkv || !wproj || !bproj || !dy || !dz || (!dparams && !t_attn_dst.p[0]) || !norm_sums || !workspace)
         return fail_arg(MSTG_E_BADARG, "window_attn_norm_bwd: null pointer");
     if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_bwd: fused kernel exists for C = 16 and 32");
     if (workspace_bytes < mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_norm_bwd: workspace too small");
@@ -1402,11 +1419,35 @@ extern "C" int mstg_window_attn_bwd(const float* x, const float* wqkv, const flo
                                     const float* dy, float* dx, float* dparams, int N, int H, int W, int C, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if (int rc = attn_check(N, H, W, C)) return rc;
-    if (!x || !wqkv || !bqkv || !wproj || !bproj || !dy || !dx || !dparams || !workspace)
+    if (!x || !wqkv || !bqkv || !wproj || !bproj || !dy || !dx || (!dparams && !t_attn_dst.p[0]) || !workspace)
         return fail_arg(MSTG_E_BADARG, "window_attn_bwd: null pointer");
     if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_bwd: fused kernel exists for C = 16 and 32");
     if (workspace_bytes < mstg_window_attn_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (C == 16) return launch_fused<16>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
     return launch_fused<32>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
+}
+
+// ---- the same two backward entry points with the reduced parameter gradients written (or added) straight into four tensors ----------
+namespace {
+struct AttnDstScope {
+    AttnDstScope(float* a, float* b, float* c, float* d, int acc) { t_attn_dst = AttnGradDst{{a, b, c, d}, acc}; }
+    ~AttnDstScope() { t_attn_dst = AttnGradDst{{nullptr, nullptr, nullptr, nullptr}, 0}; }
+};
+}  // namespace
+extern "C" int mstg_window_attn_bwd_direct(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
+                                           const float* dy, float* dx, float* dwqkv, float* dbqkv, float* dwproj, float* dbproj,
+                                           int accumulate, int N, int H, int W, int C, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dwqkv || !dbqkv || !dwproj || !dbproj) return fail_arg(MSTG_E_BADARG, "window_attn_bwd_direct: null gradient pointer");
+    AttnDstScope scope(dwqkv, dwproj, dbqkv, dbproj, accumulate);
+    return mstg_window_attn_bwd(x, wqkv, bqkv, wproj, bproj, dy, dx, nullptr, N, H, W, C, workspace, workspace_bytes, stream);
+}
+extern "C" int mstg_window_attn_norm_bwd_direct(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv,
+                                                const float* wproj, const float* bproj, const float* dy, float* dz, float* dwqkv,
+                                                float* dbqkv, float* dwproj, float* dbproj, int accumulate, float* norm_sums, int N, int H,
+                                                int W, int C, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dwqkv || !dbqkv || !dwproj || !dbproj) return fail_arg(MSTG_E_BADARG, "window_attn_norm_bwd_direct: null gradient pointer");
+    AttnDstScope scope(dwqkv, dwproj, dbqkv, dbproj, accumulate);
+    return mstg_window_attn_norm_bwd(x_raw, in_stats, wqkv, bqkv, wproj, bproj, dy, dz, nullptr, norm_sums, N, H, W, C, workspace,
+                                     workspace_bytes, stream);
 }

@@ -311,6 +311,54 @@ extern "C" int mstg_loss_mean_fwd(const float* a, const float* b, float bconst, 
 }
 
 
+// out[j] = sum_i w[j][i] * term_i for up to 8 scalar (0-dim) loss terms and up to 6 outputs (the total and the reported components
+// of enhanced_train.py:72-81, 95-131 in ONE launch instead of one torch kernel per '+' and '*'), and the backward of output 0:
+// d term_i = g * w[0][i].  Terms are weighted individually and summed left to right ((a + b) * w == a * w + b * w only up to rounding;
+// the parity bar for losses is 1e-4 relative).
+struct ScalarTerms {
+    const float* t[8];
+    float w[6][8];
+    int n, nout;
+};
+__global__ void weighted_sum_kernel(ScalarTerms a, float* __restrict__ out) {
+    const int j = threadIdx.x;
+    if (blockIdx.x == 0 && j < a.nout) {
+        float acc = 0.f;
+        for (int i = 0; i < a.n; ++i) acc += a.w[j][i] * a.t[i][0];
+        out[j] = acc;
+    }
+}
+__global__ void weighted_sum_bwd_kernel(const float* __restrict__ g, ScalarTerms a, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    if (blockIdx.x == 0 && i < a.n) out[i] = g[0] * a.w[0][i];
+}
+
+extern "C" int mstg_weighted_sum_fwd(const float* const* terms, const float* weights, int n, int nout, float* out, void* stream) {
+    if (!terms || !weights || !out || n < 1 || n > 8 || nout < 1 || nout > 6) return fail_arg(MSTG_E_BADARG, "weighted_sum_fwd: 1..8 terms, 1..6 outputs");
+    ScalarTerms a{};
+    a.n = n;
+    a.nout = nout;
+    for (int i = 0; i < n; ++i) {
+        if (!terms[i]) return fail_arg(MSTG_E_BADARG, "weighted_sum_fwd: null term");
+        a.t[i] = terms[i];
+        for (int j = 0; j < nout; ++j) a.w[j][i] = weights[j * n + i];
+    }
+    MSTG_LAUNCH(weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+    MSTG_CHECK_LAUNCH("weighted_sum_kernel");
+    return MSTG_OK;
+}
+
+extern "C" int mstg_weighted_sum_bwd(const float* g, const float* weights, int n, float* dterms, void* stream) {
+    if (!g || !weights || !dterms || n < 1 || n > 8) return fail_arg(MSTG_E_BADARG, "weighted_sum_bwd: 1..8 terms");
+    ScalarTerms a{};
+    a.n = n;
+    a.nout = 1;
+    for (int i = 0; i < n; ++i) a.w[0][i] = weights[i];
+    MSTG_LAUNCH(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, a, dterms);
+    MSTG_CHECK_LAUNCH("weighted_sum_bwd_kernel");
+    return MSTG_OK;
+}
+
 extern "C" int mstg_add(const float* a, const float* b, float* y, size_t n, void* stream) {
     if (!a || !b || !y) return fail_arg(MSTG_E_BADARG, "add: null pointer");
     if (n == 0) return MSTG_OK;

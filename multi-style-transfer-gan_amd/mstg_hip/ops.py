@@ -819,6 +819,15 @@ class WindowAttnCoreWsFn(torch.autograd.Function):
         return dqkv, None
 
 
+def _attn_grad_dst(prefs, like):
+    """Where the fused attention's four parameter gradients go: the parameters' own .grad slots (accumulating; autograd then gets
+    None and launches nothing) when ops.direct_param_grads() is on and every slot exists, else four fresh tensors."""
+    slots = [_grad_slot(p) for p in prefs]
+    if all(t is not None for t in slots):
+        return slots, True
+    return [torch.empty_like(t) for t in like], False
+
+
 class LocalAttentionFusedFn(torch.autograd.Function):
     """Whole LocalAttention (qkv 1x1 conv -> window attention -> proj 1x1 conv) in one kernel per direction, C = 16 / 32.
     x, y: NHWC (N,H,W,C); wqkv (3C,C,1,1), wproj (C,C,1,1) as stored by the reference."""
@@ -829,9 +838,10 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}, false>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_reg_fwd_kernel<{Cn}, false>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_fwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_fwd"))
+        ctx.prefs = (wqkv, bqkv, wproj, bproj)
         ctx.save_for_backward(x, wqkv, bqkv, wproj, bproj)
         return y
 
@@ -842,14 +852,12 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         dy = _req(dy, "attention grad_output")
         N, H, W, Cn = x.shape
         dx = torch.empty_like(x)
-        flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
+        outs, direct = _attn_grad_dst(ctx.prefs, (wqkv, bqkv, wproj, bproj))
         ws = _ws(lib.mstg_window_attn_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}, false>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
-            lib.mstg_window_attn_bwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), _p(flat), N, H, W, Cn, _p(ws),
-                                     ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
-        c2 = Cn * Cn
-        return (dx, flat[:3 * c2].view(3 * Cn, Cn, 1, 1), flat[4 * c2:4 * c2 + 3 * Cn], flat[3 * c2:4 * c2].view(Cn, Cn, 1, 1),
-                flat[4 * c2 + 3 * Cn:])
+        _timed(f"attn_reg_bwd_kernel<{Cn}, false>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+            lib.mstg_window_attn_bwd_direct(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), *[_p(t) for t in outs],
+                                            int(direct), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
+        return (dx, *((None,) * 4 if direct else outs))
 
 
 class NormLocalAttentionFn(torch.autograd.Function):
@@ -870,9 +878,10 @@ class NormLocalAttentionFn(torch.autograd.Function):
             _timed("norm_partial_kernel<false>", 0, 4 * x.numel(), lambda: _lib.check(
                 lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty_like(x)
-        _timed(f"attn_fused_fwd_kernel<{Cn}, true>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(f"attn_reg_fwd_kernel<{Cn}, true>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_norm_fwd"))
+        ctx.prefs = (wqkv, bqkv, wproj, bproj)
         ctx.save_for_backward(x, stats, wqkv, bqkv, wproj, bproj)
         return y
 
@@ -883,22 +892,21 @@ class NormLocalAttentionFn(torch.autograd.Function):
         dy = _req(dy, "attention grad_output")
         N, H, W, Cn = x.shape
         dz = torch.empty_like(x)
-        flat = torch.empty(4 * Cn * Cn + 4 * Cn, dtype=torch.float32, device=x.device)
+        outs, direct = _attn_grad_dst(ctx.prefs, (wqkv, bqkv, wproj, bproj))
         S = lib.mstg_window_attn_norm_sums_split()
         sums = torch.empty((N, S, 2, Cn), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_fused_bwd_kernel<{Cn}, true>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
-            lib.mstg_window_attn_norm_bwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz), _p(flat),
-                                          _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_norm_bwd"))
+        _timed(f"attn_reg_bwd_kernel<{Cn}, true>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+            lib.mstg_window_attn_norm_bwd_direct(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz),
+                                                 *[_p(t) for t in outs], int(direct), _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4,
+                                                 _stream()), "mstg_window_attn_norm_bwd"))
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _timed("norm_apply_kernel<true>", 0, 4 * x.numel() * 3, lambda: _lib.check(
                 lib.mstg_norm_bwd_apply(_p(x), _p(stats), _p(dz), _p(sums), S, _p(dx), N, H * W, Cn, ACT_RELU, _stream()),
                 "mstg_norm_bwd_apply"))
-        c2 = Cn * Cn
-        return (dx, flat[:3 * c2].view(3 * Cn, Cn, 1, 1), flat[4 * c2:4 * c2 + 3 * Cn], flat[3 * c2:4 * c2].view(Cn, Cn, 1, 1),
-                flat[4 * c2 + 3 * Cn:], None)
+        return (dx, *((None,) * 4 if direct else outs), None)
 
 
 def fused_attention_supported(Cn: int) -> bool:
@@ -1015,6 +1023,40 @@ def clip_grad_norm_flat_(flat_grad: Tensor, max_norm: float) -> Tensor:
     _lib.check(lib.mstg_clip_grad_norm(_p(flat_grad), flat_grad.numel(), float(max_norm), _p(norm), _p(ws), ws.numel() * 4, _stream()),
                "mstg_clip_grad_norm")
     return norm
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """out[j] = sum_i W[j][i] * term_i over 0-dim loss tensors in one launch; row 0 is the differentiable total (one launch for its
+    backward), further rows are reported components (no gradient): enhanced_train.py:72-81, 95-131."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        terms = [_req(t, "loss term").reshape(()) for t in terms]
+        n, nout = len(terms), len(weights)
+        out = torch.empty(nout, dtype=torch.float32, device=terms[0].device)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in terms])
+        wts = (C.c_float * (n * nout))(*[float(w) for row in weights for w in row])
+        _lib.check(_lib.load().mstg_weighted_sum_fwd(ptrs, wts, n, nout, _p(out), _stream()), "mstg_weighted_sum_fwd")
+        ctx.weights, ctx.keep = [float(w) for w in weights[0]], terms  # keep the terms alive until the launch has read them
+        total, rest = out[0], out[1:]
+        ctx.mark_non_differentiable(rest)
+        return total, rest
+
+    @staticmethod
+    def backward(ctx, g, _grest):
+        n = len(ctx.weights)
+        g = _req(g, "loss grad_output").reshape(1)
+        out = torch.empty(n, dtype=torch.float32, device=g.device)
+        wts = (C.c_float * n)(*ctx.weights)
+        _lib.check(_lib.load().mstg_weighted_sum_bwd(_p(g), wts, n, _p(out), _stream()), "mstg_weighted_sum_bwd")
+        return (None, *[out[i].reshape(()) for i in range(n)])
+
+
+def weighted_sum(terms, weights, report=()):
+    """total = sum_i weights[i] * terms[i] over 0-dim device tensors; ``report``: further weight rows whose sums are returned as a
+    (len(report),) tensor without gradient.  Returns total, or (total, reported) when ``report`` is given."""
+    total, rest = WeightedSumFn.apply((tuple(weights),) + tuple(tuple(r) for r in report), *terms)
+    return (total, rest) if report else total
 
 
 def mse_to_const(a, value: float):

@@ -494,6 +494,41 @@ def test_flat_adam_matches_torch():
     assert torch.equal(ps_hip[4].detach().cpu(), rnd(shapes[4], 74))
 
 
+def test_weighted_loss_sum_and_direct_attention_grads():
+    """ops.weighted_sum (the loss combinations of enhanced_train.py:72-81, 95-131 in one launch each way) against torch, and the fused
+    attention's parameter gradients accumulated straight into .grad (ops.direct_param_grads) against the returned-gradient path."""
+    from mstg_hip import ops
+    vals = [0.3, -1.25, 2.0, 0.5, 7.0]
+    w = [1.0, 1.0, 10.0, 2.0, 0.5]
+    t = [torch.tensor(v, device=DEV, requires_grad=True) for v in vals]
+    total, parts = ops.weighted_sum(t, w, report=((1.0, 1.0, 0, 0, 0), (0, 0, 10.0, 0, 0)))
+    tr = [torch.tensor(v, requires_grad=True) for v in vals]
+    ref = sum(wi * ti for wi, ti in zip(w, tr))
+    assert abs(float(total) - float(ref)) <= 1e-6 * abs(float(ref)) and parts.shape == (2,)
+    assert abs(float(parts[0]) - (vals[0] + vals[1])) <= 1e-6 and abs(float(parts[1]) - 10.0 * vals[2]) <= 1e-6
+    (total * 3.0).backward()
+    (ref * 3.0).backward()
+    for a_, b_ in zip(t, tr):
+        assert abs(float(a_.grad) - float(b_.grad)) <= 1e-6
+    assert not parts.requires_grad
+    # fused attention: gradients added into existing .grad slots == returned gradients added by hand
+    Cn, shape = 16, (2, 8, 12, 16)
+    x = rnd(shape, 1).to(DEV)
+    ps = [torch.nn.Parameter(v.to(DEV)) for v in (rnd((3 * Cn, Cn, 1, 1), 2, 0.25), rnd((3 * Cn,), 3, 0.1), rnd((Cn, Cn, 1, 1), 4, 0.25), rnd((Cn,), 5, 0.1))]
+    gy = rnd(shape, 6).to(DEV)
+    xg = x.clone().requires_grad_(True)
+    g_ret = torch.autograd.grad((ops.LocalAttentionFusedFn.apply(xg, *ps) * gy).sum(), [xg] + ps)
+    seeds = [rnd(tuple(p_.shape), 10 + i).to(DEV) for i, p_ in enumerate(ps)]
+    for p_, s0 in zip(ps, seeds):
+        p_.grad = s0.clone()
+    xg2 = x.clone().requires_grad_(True)
+    with ops.direct_param_grads():
+        (ops.LocalAttentionFusedFn.apply(xg2, *ps) * gy).sum().backward()
+    assert torch.equal(xg2.grad, g_ret[0])
+    for p_, s0, gr in zip(ps, seeds, g_ret[1:]):
+        assert torch.equal(p_.grad, s0 + gr)
+
+
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 16), (1, 16, 16, 32), (3, 4, 4, 16), (1, 32, 64, 32), (1, 64, 64, 16)])
 def test_local_attention_fused_vs_oracle(N, H, W, C):
     """The one-kernel LocalAttention (C = 16 / 32) against the oracle's local_attention on the CPU."""
