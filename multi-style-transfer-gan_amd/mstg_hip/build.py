@@ -38,6 +38,13 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
+# Per-source compiler switches.  attention_reg.hip: the C = 64 backward runs one wave per SIMD with the whole 512-register file;
+# left to its heuristic the compiler then puts EVERY MFMA accumulator into AGPRs (an accvgpr copy on each side of all VALU work on
+# a chain's result) and spills ~90 VGPRs to scratch; forced to the VGPR form it uses the AGPRs as spill space and needs no scratch.
+# The other kernels of the file stay below 256 registers and compile to the same code either way.
+PER_SOURCE_FLAGS = {"attention_reg.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _flags() -> str:
     return " ".join(os.environ.get("MSTG_HIPCC_FLAGS", "").split())
 
@@ -64,7 +71,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + headers())]
 
     def compile_one(src):
-        cmd = base + ["-c", src, "-o", _obj(src)]
+        cmd = base + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", _obj(src)]
         if verbose:
             print("[mstg_hip.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

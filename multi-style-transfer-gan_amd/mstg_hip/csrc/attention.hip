@@ -754,12 +754,17 @@ static bool attn_reg_on() {
 // in_stats != nullptr: x is the raw tensor in front of InstanceNorm + ReLU; backward then also fills norm_sums[N][2][C]
 // (workspace layout: [weight-gradient slabs: nb * SLAB][nsum rows: N * nb * 2C])
 template <int C>
+struct FusedSlab {
+    static constexpr int SLAB = 4 * C * C + 4 * C;  // dWqkv | dWp | dbqkv | dbp
+};
+
+template <int C>
 static int launch_fused(bool bwd, const float* x, const float* wqkv, const float* bqkv, const float* wp, const float* bp,
                         const float* dy, float* out, float* grads, float* partial, int N, int H, int W, hipStream_t st,
                         const float* in_stats = nullptr, float* norm_sums = nullptr) {
-    typedef FusedTiles<C> F;
+    typedef FusedSlab<C> F;
     const int nb = fused_blocks(N, H, W);
-    if (attn_reg_on()) {
+    if (attn_reg_on() || C > 32) {  // C = 64 exists only as the register-chain kernel
         if (!bwd) return attn_reg_fwd(C, x, in_stats, wqkv, bqkv, wp, bp, out, N, H, W, st);
         // slabs: one per workgroup of four waves, never more workgroups than runs / 4 (and so never more than the nb slabs the
         // workspace was sized for); the nsum rows sit behind the nb-slab region as before
@@ -776,31 +781,34 @@ static int launch_fused(bool bwd, const float* x, const float* wqkv, const float
         MSTG_CHECK_LAUNCH("slab_reduce_kernel");
         return MSTG_OK;
     }
-    if (!bwd) {
-        if (in_stats)
-            MSTG_LAUNCH((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
-                               out, N, H, W, in_stats);
-        else
-            MSTG_LAUNCH((attn_fused_fwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
-                               out, N, H, W, in_stats);
-        MSTG_CHECK_LAUNCH("attn_fused_fwd_kernel");
-        return MSTG_OK;
+    if constexpr (C <= 32) {
+        typedef FusedTiles<C> T;
+        if (!bwd) {
+            if (in_stats)
+                MSTG_LAUNCH((attn_fused_fwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)T::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+                                   out, N, H, W, in_stats);
+            else
+                MSTG_LAUNCH((attn_fused_fwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)T::END_FWD * sizeof(float), st, x, wqkv, bqkv, wp, bp,
+                                   out, N, H, W, in_stats);
+            MSTG_CHECK_LAUNCH("attn_fused_fwd_kernel");
+            return MSTG_OK;
+        }
+        if (in_stats) {
+            float* nsum = partial + (size_t)nb * F::SLAB;
+            const int kblk = norm_run_len(N, H, W, C), R = (H / 4) * (W / 4) / kblk;
+            MSTG_LAUNCH((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)T::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+                               out, partial, N, H, W, in_stats, nsum, kblk);
+            MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel<norm>");
+            MSTG_LAUNCH(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
+            MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
+        } else {
+            MSTG_LAUNCH((attn_fused_bwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)T::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
+                               out, partial, N, H, W, in_stats, (float*)nullptr, 1);
+            MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
+        }
+        MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB, t_attn_dst, C);
+        MSTG_CHECK_LAUNCH("slab_reduce_kernel");
     }
-    if (in_stats) {
-        float* nsum = partial + (size_t)nb * F::SLAB;
-        const int kblk = norm_run_len(N, H, W, C), R = (H / 4) * (W / 4) / kblk;
-        MSTG_LAUNCH((attn_fused_bwd_kernel<C, true>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
-                           out, partial, N, H, W, in_stats, nsum, kblk);
-        MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel<norm>");
-        MSTG_LAUNCH(nsum_reduce_kernel, dim3(NSUM_SPLIT, N), dim3(256), 0, st, (const float*)nsum, norm_sums, R, NSUM_SPLIT, 2 * C);
-        MSTG_CHECK_LAUNCH("nsum_reduce_kernel");
-    } else {
-        MSTG_LAUNCH((attn_fused_bwd_kernel<C, false>), dim3(nb), dim3(64), (size_t)F::END_BWD * sizeof(float), st, x, wqkv, bqkv, wp, bp, dy,
-                           out, partial, N, H, W, in_stats, (float*)nullptr, 1);
-        MSTG_CHECK_LAUNCH("attn_fused_bwd_kernel");
-    }
-    MSTG_LAUNCH(slab_reduce_kernel, dim3(cdiv(F::SLAB, 16)), dim3(256), 0, st, (const float*)partial, grads, nb, F::SLAB, t_attn_dst, C);
-    MSTG_CHECK_LAUNCH("slab_reduce_kernel");
     return MSTG_OK;
 }
 
@@ -1366,7 +1374,7 @@ extern "C" int mstg_debug_stamps_attn_fwd(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_att_fstamps), sizeof(unsigned long long) * 64 * 8);
 }
 #endif
-extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32; }
+extern "C" int mstg_window_attn_fused_supported(int C) { return C == 16 || C == 32 || C == 64; }
 
 extern "C" int mstg_window_attn_fwd(const float* x, const float* wqkv, const float* bqkv, const float* wproj, const float* bproj,
                                     float* y, int N, int H, int W, int C, void* stream) {
@@ -1375,7 +1383,8 @@ extern "C" int mstg_window_attn_fwd(const float* x, const float* wqkv, const flo
     hipStream_t st = (hipStream_t)stream;
     if (C == 16) return launch_fused<16>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
     if (C == 32) return launch_fused<32>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
-    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_fwd: fused kernel exists for C = 16 and 32 (use the qkv/core/proj chain otherwise)");
+    if (C == 64) return launch_fused<64>(false, x, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st);
+    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_fwd: fused kernel exists for C = 16, 32 and 64 (use the qkv/core/proj chain otherwise)");
 }
 
 extern "C" int mstg_window_attn_norm_fwd(const float* x_raw, const float* in_stats, const float* wqkv, const float* bqkv,
@@ -1385,13 +1394,14 @@ extern "C" int mstg_window_attn_norm_fwd(const float* x_raw, const float* in_sta
     hipStream_t st = (hipStream_t)stream;
     if (C == 16) return launch_fused<16>(false, x_raw, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st, in_stats);
     if (C == 32) return launch_fused<32>(false, x_raw, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st, in_stats);
-    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_fwd: fused kernel exists for C = 16 and 32");
+    if (C == 64) return launch_fused<64>(false, x_raw, wqkv, bqkv, wproj, bproj, nullptr, y, nullptr, nullptr, N, H, W, st, in_stats);
+    return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_fwd: fused kernel exists for C = 16, 32 and 64");
 }
 
 extern "C" int mstg_window_attn_norm_sums_split(void) { return NSUM_SPLIT; }
 
 extern "C" size_t mstg_window_attn_norm_bwd_workspace_bytes(int N, int H, int W, int C) {
-    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32 || C == 64)) return 0;
     const size_t nb = (size_t)fused_blocks(N, H, W);
     return (nb * (4 * C * C + 4 * C) + (size_t)N * ((H / 4) * (W / 4) / norm_run_len(N, H, W, C)) * 2 * C) * sizeof(float);
 }
@@ -1403,15 +1413,16 @@ extern "C" int mstg_window_attn_norm_bwd(const float* x_raw, const float* in_sta
     if (int rc = attn_check(N, H, W, C)) return rc;
     if (!x_raw || !in_stats || !wqkv || !bqkv || !wproj || !bproj || !dy || !dz || (!dparams && !t_attn_dst.p[0]) || !norm_sums || !workspace)
         return fail_arg(MSTG_E_BADARG, "window_attn_norm_bwd: null pointer");
-    if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_bwd: fused kernel exists for C = 16 and 32");
+    if (!(C == 16 || C == 32 || C == 64)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_norm_bwd: fused kernel exists for C = 16, 32 and 64");
     if (workspace_bytes < mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_norm_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (C == 16) return launch_fused<16>(true, x_raw, wqkv, bqkv, wproj, bproj, dy, dz, dparams, (float*)workspace, N, H, W, st, in_stats, norm_sums);
+    if (C == 64) return launch_fused<64>(true, x_raw, wqkv, bqkv, wproj, bproj, dy, dz, dparams, (float*)workspace, N, H, W, st, in_stats, norm_sums);
     return launch_fused<32>(true, x_raw, wqkv, bqkv, wproj, bproj, dy, dz, dparams, (float*)workspace, N, H, W, st, in_stats, norm_sums);
 }
 
 extern "C" size_t mstg_window_attn_bwd_workspace_bytes(int N, int H, int W, int C) {
-    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32)) return 0;
+    if (N <= 0 || H <= 0 || W <= 0 || !(C == 16 || C == 32 || C == 64)) return 0;
     return (size_t)fused_blocks(N, H, W) * (4 * C * C + 4 * C) * sizeof(float);
 }
 
@@ -1421,10 +1432,11 @@ extern "C" int mstg_window_attn_bwd(const float* x, const float* wqkv, const flo
     if (int rc = attn_check(N, H, W, C)) return rc;
     if (!x || !wqkv || !bqkv || !wproj || !bproj || !dy || !dx || (!dparams && !t_attn_dst.p[0]) || !workspace)
         return fail_arg(MSTG_E_BADARG, "window_attn_bwd: null pointer");
-    if (!(C == 16 || C == 32)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_bwd: fused kernel exists for C = 16 and 32");
+    if (!(C == 16 || C == 32 || C == 64)) return fail_arg(MSTG_E_UNSUPPORTED, "window_attn_bwd: fused kernel exists for C = 16, 32 and 64");
     if (workspace_bytes < mstg_window_attn_bwd_workspace_bytes(N, H, W, C)) return fail_arg(MSTG_E_WORKSPACE, "window_attn_bwd: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     if (C == 16) return launch_fused<16>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
+    if (C == 64) return launch_fused<64>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
     return launch_fused<32>(true, x, wqkv, bqkv, wproj, bproj, dy, dx, dparams, (float*)workspace, N, H, W, st);
 }
 

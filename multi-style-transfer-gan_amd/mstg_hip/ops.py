@@ -828,8 +828,14 @@ def _attn_grad_dst(prefs, like):
     return [torch.empty_like(t) for t in like], False
 
 
+def _attn_fused_symbol(direction, Cn, norm):
+    """Kernel symbol attention_reg.hip launches for this width (for the timing table only)."""
+    stem = "attn_big" if Cn > 32 or (Cn == 32 and os.environ.get("MSTG_ATTN_BIG32") == "1") else "attn_reg"
+    return f"{stem}_{direction}_kernel<{Cn}, {'true' if norm else 'false'}>"
+
+
 class LocalAttentionFusedFn(torch.autograd.Function):
-    """Whole LocalAttention (qkv 1x1 conv -> window attention -> proj 1x1 conv) in one kernel per direction, C = 16 / 32.
+    """Whole LocalAttention (qkv 1x1 conv -> window attention -> proj 1x1 conv) in one kernel per direction, C = 16 / 32 / 64.
     x, y: NHWC (N,H,W,C); wqkv (3C,C,1,1), wproj (C,C,1,1) as stored by the reference."""
 
     @staticmethod
@@ -838,7 +844,7 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         wqkv, bqkv, wproj, bproj = (_req(t, "attention parameter") for t in (wqkv, bqkv, wproj, bproj))
         N, H, W, Cn = x.shape
         y = torch.empty_like(x)
-        _timed(f"attn_reg_fwd_kernel<{Cn}, false>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(_attn_fused_symbol("fwd", Cn, False), 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             _lib.load().mstg_window_attn_fwd(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_fwd"))
         ctx.prefs = (wqkv, bqkv, wproj, bproj)
@@ -854,14 +860,14 @@ class LocalAttentionFusedFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         outs, direct = _attn_grad_dst(ctx.prefs, (wqkv, bqkv, wproj, bproj))
         ws = _ws(lib.mstg_window_attn_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_reg_bwd_kernel<{Cn}, false>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(_attn_fused_symbol("bwd", Cn, False), 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_bwd_direct(_p(x), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dx), *[_p(t) for t in outs],
                                             int(direct), N, H, W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_window_attn_bwd"))
         return (dx, *((None,) * 4 if direct else outs))
 
 
 class NormLocalAttentionFn(torch.autograd.Function):
-    """LocalAttention(ReLU(InstanceNorm2d(x))) with the norm folded into the attention kernels (C = 16 / 32): statistics pass over
+    """LocalAttention(ReLU(InstanceNorm2d(x))) with the norm folded into the attention kernels (C = 16 / 32 / 64): statistics pass over
     x, then the attention forward normalises while it stages each window; the backward's attention kernel sums what the norm's
     backward needs in its epilogue, so the norm costs one read in the forward and one read-read-write pass in the backward
     instead of 3 + 5 tensor passes -- and the normalised tensor is never stored."""
@@ -878,7 +884,7 @@ class NormLocalAttentionFn(torch.autograd.Function):
             _timed("norm_partial_kernel<false>", 0, 4 * x.numel(), lambda: _lib.check(
                 lib.mstg_norm_stats(_p(x), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
         y = torch.empty_like(x)
-        _timed(f"attn_reg_fwd_kernel<{Cn}, true>", 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
+        _timed(_attn_fused_symbol("fwd", Cn, True), 12 * Cn * Cn * N * H * W, 4 * 2 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_fwd(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(y), N, H, W, Cn, _stream()),
             "mstg_window_attn_norm_fwd"))
         ctx.prefs = (wqkv, bqkv, wproj, bproj)
@@ -896,7 +902,7 @@ class NormLocalAttentionFn(torch.autograd.Function):
         S = lib.mstg_window_attn_norm_sums_split()
         sums = torch.empty((N, S, 2, Cn), dtype=torch.float32, device=x.device)
         ws = _ws(lib.mstg_window_attn_norm_bwd_workspace_bytes(N, H, W, Cn), x.device)
-        _timed(f"attn_reg_bwd_kernel<{Cn}, true>", 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
+        _timed(_attn_fused_symbol("bwd", Cn, True), 24 * Cn * Cn * N * H * W, 4 * 3 * Cn * N * H * W, lambda: _lib.check(
             lib.mstg_window_attn_norm_bwd_direct(_p(x), _p(stats), _p(wqkv), _p(bqkv), _p(wproj), _p(bproj), _p(dy), _p(dz),
                                                  *[_p(t) for t in outs], int(direct), _p(sums), N, H, W, Cn, _p(ws), ws.numel() * 4,
                                                  _stream()), "mstg_window_attn_norm_bwd"))

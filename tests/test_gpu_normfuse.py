@@ -29,7 +29,8 @@ def rnd(shape, seed, scale=1.0):
     return torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * scale
 
 
-@pytest.mark.parametrize("Cn,N,H,W", [(16, 3, 16, 24), (32, 2, 24, 16), (16, 5, 64, 64), (32, 1, 8, 8)])
+@pytest.mark.parametrize("Cn,N,H,W", [(16, 3, 16, 24), (32, 2, 24, 16), (16, 5, 64, 64), (32, 1, 8, 8), (64, 2, 24, 16), (64, 5, 64, 64),
+                                      (64, 1, 4, 4)])
 def test_norm_attention_fused_vs_chain_and_torch(Cn, N, H, W):
     """IN + ReLU folded into the fused attention kernels: forward bit-identical to norm kernel + attention kernel (same arithmetic,
     same statistics), backward within fp32 summation-order noise of it; both against the oracle (torch fp32, CPU)."""
@@ -250,17 +251,21 @@ def test_ms_fusion_output_statistics_and_apply(N, H, W, Cn):
 @pytest.mark.parametrize("env", ["MSTG_NORM_ATTN=0", "MSTG_NORM_EPILOGUE=0", "MSTG_NORM_FUSION=0", "MSTG_P32=0", "MSTG_NORM_BSUMS=0", "MSTG_NO_PACK_CACHE=1"])
 def test_generator_same_with_every_norm_folding_switched_off(env, monkeypatch):
     """The folded InstanceNorms and the persistent kernels are optimisations of the same arithmetic: the generator's output and all
-    parameter gradients with each of them switched off agree with the default path: forward <= 5e-5, gradients <= 1e-3 aggregate (the
-    epilogue statistics and the attention epilogue's sums differ from the pass-based ones by fp32 rounding, ~1e-6, which thirteen chained
-    InstanceNorms and the ReLU masks amplify exactly as they amplify any other fp32 summation order: DESIGN.md section 4)."""
+    parameter gradients with each of them switched off agree with the default path.  Forward: <= 5e-5 on every draw.  Gradients:
+    two fp32 evaluations whose roundings differ anywhere (epilogue statistics vs a statistics pass, ~1e-6) either flip no ReLU mask
+    of the thirteen chained InstanceNorms -- then their aggregate gradients agree to ~1e-5 -- or flip one, which moves the aggregate
+    gradient by 1e-3 .. 1e-2 on THAT draw (measured: the distances are bimodal, about half of the draws of this shape flip;
+    DESIGN.md section 4; the size of the effect against fp64 is pinned by test_train_step_gradient_distance_distribution).  So the
+    statement is made over sixteen input draws: at least two are in the flip-free mode and agree to <= 5e-5 (a systematic difference
+    of the two paths, however small, would show on every draw), and no draw is beyond 2e-2 (a wiring error -- a wrong tensor, a
+    missing term -- is O(1))."""
     import enhanced_generator
     from mstg_hip import ops
     from oracle import restatement as R
     sd = R.make_state_dict(R.generator_spec(16), 77)
-    x = R.make_input((2, 3, 64, 64), 78).to(DEV)
-    gy = rnd((2, 3, 64, 64), 79).to(DEV)
+    k, v = env.split("=")
 
-    def run():
+    def run(x, gy):
         torch.manual_seed(0)
         net = enhanced_generator.EnhancedGenerator(channels=16, num_transformer_blocks=0).to(DEV)
         net.load_state_dict(sd)
@@ -268,18 +273,25 @@ def test_generator_same_with_every_norm_folding_switched_off(env, monkeypatch):
         grads = torch.autograd.grad((y * gy).sum(), list(net.parameters()), allow_unused=True)
         return y.detach().cpu(), [None if g_ is None else g_.cpu() for g_ in grads], [n_ for n_, _ in net.named_parameters()]
 
-    y0, g0, names = run()
-    k, v = env.split("=")
-    monkeypatch.setenv(k, v)
-    ops.refresh_env()
-    y1, g1, _ = run()
-    monkeypatch.delenv(k)
-    ops.refresh_env()
-    report(f"generator output with {env}", rel_l2(y1, y0), 5e-5)
-    num = den = 0.0
-    for n_, a_, b_ in zip(names, g1, g0):
-        if a_ is None or b_ is None:
-            assert a_ is None and b_ is None, n_
-            continue
-        num += float((a_ - b_).pow(2).sum()); den += float(b_.pow(2).sum())
-    report(f"generator gradients (aggregate) with {env}", (num / max(den, 1e-300)) ** 0.5, 1e-3)
+    dists = []
+    for draw in range(16):
+        x = R.make_input((2, 3, 64, 64), 78 + 10 * draw).to(DEV)
+        gy = rnd((2, 3, 64, 64), 79 + 10 * draw).to(DEV)
+        y0, g0, names = run(x, gy)
+        monkeypatch.setenv(k, v)
+        ops.refresh_env()
+        y1, g1, _ = run(x, gy)
+        monkeypatch.delenv(k)
+        ops.refresh_env()
+        report(f"generator output with {env}, draw {draw}", rel_l2(y1, y0), 5e-5)
+        num = den = 0.0
+        for n_, a_, b_ in zip(names, g1, g0):
+            if a_ is None or b_ is None:
+                assert a_ is None and b_ is None, n_
+                continue
+            num += float((a_ - b_).pow(2).sum()); den += float(b_.pow(2).sum())
+        dists.append((num / max(den, 1e-300)) ** 0.5)
+    dists.sort()
+    print(f"  [parity] generator gradients (aggregate) with {env}: " + " ".join(f"{d:.1e}" for d in dists))
+    report(f"generator gradients (aggregate) with {env}, second best of 16 draws", dists[1], 5e-5)
+    report(f"generator gradients (aggregate) with {env}, worst of 16 draws", dists[-1], 2e-2)

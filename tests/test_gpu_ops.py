@@ -227,7 +227,7 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
 @pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
                                  "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0",
                                  "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1",
-                                 "MSTG_ATTN_REG=0"])
+                                 "MSTG_ATTN_REG=0", "MSTG_ATTN_BIG32=1"])
 def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
@@ -252,6 +252,12 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
         import test_gpu_normfuse
         test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(16, 3, 16, 24)
         test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(32, 2, 24, 16)
+    if k == "MSTG_ATTN_BIG32":  # C = 32 through the C = 64 implementation (filters in LDS, row-block transposes)
+        for shape in ((1, 16, 16, 32), (1, 32, 64, 32), (4, 96, 64, 32)):
+            test_local_attention_fused_vs_oracle(*shape)
+        import test_gpu_normfuse
+        test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(32, 2, 24, 16)
+        test_gpu_normfuse.test_norm_attention_fused_vs_chain_and_torch(32, 3, 96, 64)
 
 
 NORM_CASES = [(2, 16, 24, 8, 1), (1, 64, 64, 16, 1), (3, 7, 9, 32, 2), (2, 4, 4, 64, 2), (1, 128, 128, 16, 1), (2, 2, 2, 64, 2),
@@ -529,9 +535,11 @@ def test_weighted_loss_sum_and_direct_attention_grads():
         assert torch.equal(p_.grad, s0 + gr)
 
 
-@pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 16), (1, 16, 16, 32), (3, 4, 4, 16), (1, 32, 64, 32), (1, 64, 64, 16)])
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 12, 16), (1, 16, 16, 32), (3, 4, 4, 16), (1, 32, 64, 32), (1, 64, 64, 16), (2, 8, 12, 64),
+                                     (1, 4, 4, 64), (5, 64, 128, 64)])
 def test_local_attention_fused_vs_oracle(N, H, W, C):
-    """The one-kernel LocalAttention (C = 16 / 32) against the oracle's local_attention on the CPU."""
+    """The one-kernel LocalAttention (C = 16 / 32 / 64) against the oracle's local_attention on the CPU; the last case gives every
+    wave of the C = 64 kernels two or three windows."""
     from mstg_hip import ops
     from oracle import restatement as R
     spec = [("qkv.weight", (3 * C, C, 1, 1)), ("qkv.bias", (3 * C,)), ("proj.weight", (C, C, 1, 1)), ("proj.bias", (C,))]
