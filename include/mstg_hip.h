@@ -284,6 +284,18 @@ int mstg_spectral_norm_fwd(const float* w, float* u, float* v, float* w_out, flo
                            int K, float eps, int training, void* workspace, size_t workspace_bytes, void* stream);
 int mstg_spectral_norm_bwd(const float* dwn, const float* w, const float* u, const float* v, const float* sigma, float* dw,
                            int accumulate /* != 0: dw += */, int M, int K, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for up to mstg_spectral_norm_group_max() weights at once -- every convolution of one EnhancedDiscriminator forward
+ * (enhanced_generator.py:236-271: seven weights, each normalised by its own hook before its convolution runs) in three launches
+ * (two in the backward) instead of thirteen.  Arrays hold `count` entries; per weight the semantics are those of the calls above.
+ * u_save / v_save may be null as a whole; sigma (fwd) is `count` floats, sigma (bwd) `count` pointers to them. */
+int mstg_spectral_norm_group_max(void);
+size_t mstg_spectral_norm_group_workspace_bytes(int count, const int* M, const int* K);
+int mstg_spectral_norm_group_fwd(int count, const float* const* w, float* const* u, float* const* v, float* const* w_out, float* sigma,
+                                 float* const* u_save, float* const* v_save, const int* M, const int* K, float eps, int training,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+int mstg_spectral_norm_group_bwd(int count, const float* const* dwn, const float* const* w, const float* const* u,
+                                 const float* const* v, const float* const* sigma, float* const* dw, const int* accumulate, const int* M,
+                                 const int* K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Build-defined multi-style perceptual loss pieces.  The reference has NO implementation of them (the

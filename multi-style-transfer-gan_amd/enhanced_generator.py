@@ -276,15 +276,24 @@ class EnhancedDiscriminator(nn.Module):
         self.batch_head = nn.Sequential(HipConv2d(C * 8, 1, 4, 1, 1), nn.AdaptiveAvgPool2d(1))
         self.structure_head = nn.Sequential(HipConv2d(C * 8, C * 8, 3, 1, 1), HipInstanceNorm2d(C * 8), HipLeakyReLU(0.2),
                                             HipConv2d(C * 8, 1, 4, 1, 1))
+        fused = []
         for m in self.modules():  # reference :269-271 -- the hook recomputes W/sigma (one power iteration) per forward
             if isinstance(m, nn.Conv2d):
                 nn.utils.spectral_norm(m)
                 if os.environ.get("MSTG_TORCH_SPECTRAL_NORM", "0") != "1":
-                    ops.install_fused_spectral_norm(m)  # same parameters / buffers / state_dict; one launch instead of ~14
+                    fused.append(ops.install_fused_spectral_norm(m))  # same parameters / buffers / state_dict; one launch instead of ~14
+        # all seven weights of a forward in one grouped call (three launches) ahead of the first convolution; MSTG_SN_GROUP=0 leaves
+        # every convolution to its own hook
+        self._sn_grouped = bool(fused) and all(fused)
+
+    def _sn_convs(self):
+        return [self.main[0], self.main[2], self.main[5], self.main[8], self.batch_head[0], self.structure_head[0], self.structure_head[3]]
 
     def forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"EnhancedDiscriminator expects (N,3,H,W), got {tuple(x.shape)}")
+        if self._sn_grouped and os.environ.get("MSTG_SN_GROUP", "1") != "0":
+            ops.spectral_norm_group(self._sn_convs())
         m = self.main
         h = ops.activation(m[0](x, nhwc=True, x_nchw=True), ACT_LEAKY02)
         for ci in (2, 5, 8):

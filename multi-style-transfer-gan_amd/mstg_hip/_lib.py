@@ -104,6 +104,10 @@ SIGNATURES = {
     "mstg_spectral_norm_workspace_bytes": (_sz, [_i, _i]),
     "mstg_spectral_norm_fwd": (_i, [_fp] * 7 + [_i, _i, _f, _i, _vp, _sz, _vp]),
     "mstg_spectral_norm_bwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _vp, _sz, _vp]),
+    "mstg_spectral_norm_group_max": (_i, []),
+    "mstg_spectral_norm_group_workspace_bytes": (_sz, [_i, _vp, _vp]),
+    "mstg_spectral_norm_group_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _fp, _vp, _vp, _vp, _vp, _f, _i, _vp, _sz, _vp]),
+    "mstg_spectral_norm_group_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "mstg_f16_conv_plan_bytes": (_sz, [_hp]),
     "mstg_f16_conv_pack": (_i, [_hp] + [_fp] * 8 + [_vp, _sz, _vp]),
     "mstg_f16_conv_partial_bytes": (_sz, [_hp]),

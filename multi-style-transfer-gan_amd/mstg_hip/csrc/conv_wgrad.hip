@@ -967,13 +967,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int idx = (blockIdx.x * 16 + q) * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     if ((pstride & 3) == 0) {
-        if (idx < nout)
-            for (int sp = row; sp < S; sp += 16) sum += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * pstride + idx);
-    } else {
-        for (int sp = row; sp < S; sp += 16)
+        if (idx < nout) {  // eight loads in flight per trip; the additions keep the order sp = row, row + 16, ...
+            int sp = row;
+            for (; sp + 7 * 16 < S; sp += 8 * 16) {
+                f32x4 v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const f32x4*>(partial + (size_t)(sp + 16 * k) * pstride + idx);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sum += v[k];
+            }
+            for (; sp < S; sp += 16) sum += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * pstride + idx);
+        }
+    } else if (idx < nout) {  // slab stride not a multiple of four floats (three-channel layers): 4-byte loads, same batching and order
+        const int nc = nout - idx < 4 ? nout - idx : 4;
+        int sp = row;
+        for (; sp + 7 * 16 < S; sp += 8 * 16) {
+            f32x4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[k][c] = c < nc ? partial[(size_t)(sp + 16 * k) * pstride + idx + c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
+        }
+        for (; sp < S; sp += 16)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (idx + c < nout) sum[c] += partial[(size_t)sp * pstride + idx + c];
+                if (c < nc) sum[c] += partial[(size_t)sp * pstride + idx + c];
     }
     sh[row][q] = sum;
     __syncthreads();

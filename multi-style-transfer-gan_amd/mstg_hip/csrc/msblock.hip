@@ -559,8 +559,17 @@ __global__ __launch_bounds__(256) void wgrad_ms_reduce_kernel(const float* __res
     const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + e;
     float sum = 0.f;
-    if (idx < PSTRIDE)
-        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    if (idx < PSTRIDE) {  // eight loads in flight per trip; the additions keep the order sp = row, row + 16, ...
+        int sp = row;
+        for (; sp + 7 * 16 < S; sp += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(sp + 16 * k) * PSTRIDE + idx];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
+        }
+        for (; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    }
     sh[row][e] = sum;
     __syncthreads();
     if (row != 0 || idx >= PSTRIDE) return;
@@ -597,8 +606,17 @@ __global__ __launch_bounds__(256) void wgrad_msp_reduce_kernel(const float* __re
     const int e = threadIdx.x & 15, row = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + e;
     float sum = 0.f;
-    if (idx < PSTRIDE)
-        for (int sp = row; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    if (idx < PSTRIDE) {  // eight loads in flight per trip; the additions keep the order sp = row, row + 16, ...
+        int sp = row;
+        for (; sp + 7 * 16 < S; sp += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(size_t)(sp + 16 * k) * PSTRIDE + idx];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
+        }
+        for (; sp < S; sp += 16) sum += partial[(size_t)sp * PSTRIDE + idx];
+    }
     sh[row][e] = sum;
     __syncthreads();
     if (row != 0 || idx >= PSTRIDE) return;

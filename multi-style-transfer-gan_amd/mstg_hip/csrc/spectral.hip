@@ -119,9 +119,9 @@ __global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(const float* __
 constexpr int SN_G = 16;
 
 // A: workgroup b owns rows [m0, m1): tpart[b][k] = sum_{m in slab} W[m][k] u[m]
-__global__ __launch_bounds__(256) void spectral_a_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ scratch,
-                                                         int M, int K) {
-    const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G, m0 = b * rows, m1 = min(M, m0 + rows);
+__device__ __forceinline__ void spectral_a_body(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ scratch, int M,
+                                                int K, int b) {
+    const int rows = (M + SN_G - 1) / SN_G, m0 = b * rows, m1 = min(M, m0 + rows);
     float* tpart = scratch + (size_t)b * K;
     for (int k = threadIdx.x; k < K; k += 256) {
         float t = 0.f;
@@ -129,13 +129,16 @@ __global__ __launch_bounds__(256) void spectral_a_kernel(const float* __restrict
         tpart[k] = t;
     }
 }
+__global__ __launch_bounds__(256) void spectral_a_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ scratch,
+                                                         int M, int K) {
+    spectral_a_body(W, u, scratch, M, K, blockIdx.x);
+}
 
 // B: every workgroup rebuilds t = sum_b tpart[b] and v = t / max(||t||, eps) (workgroup 0 stores v), then s[m] = W[m] . v for
 // its own rows
-__global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict__ W, float* __restrict__ v, float* __restrict__ scratch,
-                                                         int M, int K, float eps, int training, float* __restrict__ v_save) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // sv[K] | red[32]
-    float* sv = sm;
+__device__ __forceinline__ void spectral_b_body(const float* __restrict__ W, float* __restrict__ v, float* __restrict__ scratch, int M, int K,
+                                                float eps, int training, float* __restrict__ v_save, float* sm, int b) {
+    float* sv = sm;  // sv[K] | red[32]
     float* red = sm + K;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float ss = 0.f;
@@ -155,13 +158,13 @@ __global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict
         for (int k = tid; k < K; k += 256) {
             const float t = sv[k] / nv;
             sv[k] = t;
-            if (blockIdx.x == 0) v[k] = t;
+            if (b == 0) v[k] = t;
         }
     }
     __syncthreads();
-    if (v_save && blockIdx.x == 0)
+    if (v_save && b == 0)
         for (int k = tid; k < K; k += 256) v_save[k] = sv[k];
-    const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G, m0 = b * rows, m1 = min(M, m0 + rows);
+    const int rows = (M + SN_G - 1) / SN_G, m0 = b * rows, m1 = min(M, m0 + rows);
     float* s_out = scratch + (size_t)SN_G * K;
     for (int m = m0 + wave; m < m1; m += 4) {
         float p = 0.f;
@@ -170,13 +173,17 @@ __global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict
         if (lane == 0) s_out[m] = p;
     }
 }
+__global__ __launch_bounds__(256) void spectral_b_kernel(const float* __restrict__ W, float* __restrict__ v, float* __restrict__ scratch,
+                                                         int M, int K, float eps, int training, float* __restrict__ v_save) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    spectral_b_body(W, v, scratch, M, K, eps, training, v_save, sm, blockIdx.x);
+}
 
 // C: every workgroup rebuilds ||s||, u = s / max(||s||, eps) and sigma = u . s (workgroup 0 stores u and sigma; eval mode
 // keeps u), then writes its rows of W / sigma
-__global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict__ W, float* __restrict__ u, const float* __restrict__ scratch,
-                                                         float* __restrict__ Wn, float* __restrict__ sigma_out, int M, int K, float eps,
-                                                         int training, float* __restrict__ u_save) {
-    __shared__ float red[32];
+__device__ __forceinline__ void spectral_c_body(const float* __restrict__ W, float* __restrict__ u, const float* __restrict__ scratch,
+                                                float* __restrict__ Wn, float* __restrict__ sigma_out, int M, int K, float eps, int training,
+                                                float* __restrict__ u_save, float* red, int b) {
     const float* s_in = scratch + (size_t)SN_G * K;
     const int tid = threadIdx.x;
     float sigma;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict
         float sp = 0.f;
         for (int m = tid; m < M; m += 256) {
             const float un = s_in[m] / nu;
-            if (blockIdx.x == 0) {
+            if (b == 0) {
                 u[m] = un;
                 if (u_save) u_save[m] = un;
             }
@@ -198,41 +205,105 @@ __global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict
         float sp = 0.f;
         for (int m = tid; m < M; m += 256) {
             sp = fmaf(u[m], s_in[m], sp);
-            if (u_save && blockIdx.x == 0) u_save[m] = u[m];
+            if (u_save && b == 0) u_save[m] = u[m];
         }
         sigma = block_sum_1024(sp, red);
     }
-    if (blockIdx.x == 0 && tid == 0) *sigma_out = sigma;
-    const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G;
+    if (b == 0 && tid == 0) *sigma_out = sigma;
+    const int rows = (M + SN_G - 1) / SN_G;
     const size_t e0 = (size_t)b * rows * K, e1 = min((size_t)M * K, e0 + (size_t)rows * K);
     for (size_t e = e0 + tid; e < e1; e += 256) Wn[e] = W[e] / sigma;
 }
+__global__ __launch_bounds__(256) void spectral_c_kernel(const float* __restrict__ W, float* __restrict__ u, const float* __restrict__ scratch,
+                                                         float* __restrict__ Wn, float* __restrict__ sigma_out, int M, int K, float eps,
+                                                         int training, float* __restrict__ u_save) {
+    __shared__ float red[32];
+    spectral_c_body(W, u, scratch, Wn, sigma_out, M, K, eps, training, u_save, red, blockIdx.x);
+}
 
 // backward, large matrices: A = per-workgroup partial of sum(dWn * W); B = every workgroup re-sums the partials, writes its rows
-__global__ __launch_bounds__(256) void spectral_bwd_a_kernel(const float* __restrict__ dWn, const float* __restrict__ W,
-                                                             float* __restrict__ scratch, int M, int K) {
-    __shared__ float red[32];
-    const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G;
+__device__ __forceinline__ void spectral_bwd_a_body(const float* __restrict__ dWn, const float* __restrict__ W, float* __restrict__ scratch,
+                                                    int M, int K, float* red, int b) {
+    const int rows = (M + SN_G - 1) / SN_G;
     const size_t e0 = (size_t)b * rows * K, e1 = min((size_t)M * K, e0 + (size_t)rows * K);
     float dot = 0.f;
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) dot = fmaf(dWn[e], W[e], dot);
     dot = block_sum_1024(dot, red);
     if (threadIdx.x == 0) scratch[b] = dot;
 }
-__global__ __launch_bounds__(256) void spectral_bwd_b_kernel(const float* __restrict__ dWn, const float* __restrict__ u,
-                                                             const float* __restrict__ v, const float* __restrict__ sigma_p,
-                                                             const float* __restrict__ scratch, float* __restrict__ dW, int M, int K,
-                                                             int accumulate) {
+__global__ __launch_bounds__(256) void spectral_bwd_a_kernel(const float* __restrict__ dWn, const float* __restrict__ W,
+                                                             float* __restrict__ scratch, int M, int K) {
+    __shared__ float red[32];
+    spectral_bwd_a_body(dWn, W, scratch, M, K, red, blockIdx.x);
+}
+__device__ __forceinline__ void spectral_bwd_b_body(const float* __restrict__ dWn, const float* __restrict__ u, const float* __restrict__ v,
+                                                    const float* __restrict__ sigma_p, const float* __restrict__ scratch,
+                                                    float* __restrict__ dW, int M, int K, int accumulate, int b) {
     float dot = 0.f;
     for (int g = 0; g < SN_G; ++g) dot += scratch[g];
     const float sigma = *sigma_p, c = dot / (sigma * sigma);
-    const int b = blockIdx.x, rows = (M + SN_G - 1) / SN_G;
+    const int rows = (M + SN_G - 1) / SN_G;
     const size_t e0 = (size_t)b * rows * K, e1 = min((size_t)M * K, e0 + (size_t)rows * K);
     for (size_t e = e0 + threadIdx.x; e < e1; e += 256) {
         const int m = (int)(e / K), k = (int)(e - (size_t)m * K);
         const float r = dWn[e] / sigma - c * u[m] * v[k];
         dW[e] = accumulate ? dW[e] + r : r;
     }
+}
+__global__ __launch_bounds__(256) void spectral_bwd_b_kernel(const float* __restrict__ dWn, const float* __restrict__ u,
+                                                             const float* __restrict__ v, const float* __restrict__ sigma_p,
+                                                             const float* __restrict__ scratch, float* __restrict__ dW, int M, int K,
+                                                             int accumulate) {
+    spectral_bwd_b_body(dWn, u, v, sigma_p, scratch, dW, M, K, accumulate, blockIdx.x);
+}
+
+// ---- a group of weights (every convolution of one discriminator forward) in the same three / two launches: blockIdx.y = weight --------
+// A discriminator forward normalises seven weights; one at a time that is 13 launches of a few microseconds each (and their backward
+// mirror), 160 of the train step's launches.  The split kernels above take any shape (a workgroup whose row slab is empty writes
+// zeros / nothing), so the whole group runs through them at once.
+constexpr int SN_MAX_GROUP = 8;
+struct SnGroup {
+    const float* w[SN_MAX_GROUP];
+    float* u[SN_MAX_GROUP];
+    float* v[SN_MAX_GROUP];
+    float* wn[SN_MAX_GROUP];
+    float* us[SN_MAX_GROUP];
+    float* vs[SN_MAX_GROUP];
+    float* scratch[SN_MAX_GROUP];
+    int M[SN_MAX_GROUP], K[SN_MAX_GROUP];
+};
+struct SnGroupBwd {
+    const float* dwn[SN_MAX_GROUP];
+    const float* w[SN_MAX_GROUP];
+    const float* u[SN_MAX_GROUP];
+    const float* v[SN_MAX_GROUP];
+    const float* sigma[SN_MAX_GROUP];
+    float* dw[SN_MAX_GROUP];
+    float* scratch[SN_MAX_GROUP];
+    int M[SN_MAX_GROUP], K[SN_MAX_GROUP], accumulate[SN_MAX_GROUP];
+};
+__global__ __launch_bounds__(256) void spectral_group_a_kernel(const SnGroup g) {
+    const int j = blockIdx.y;
+    spectral_a_body(g.w[j], g.u[j], g.scratch[j], g.M[j], g.K[j], blockIdx.x);
+}
+__global__ __launch_bounds__(256) void spectral_group_b_kernel(const SnGroup g, float eps, int training) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int j = blockIdx.y;
+    spectral_b_body(g.w[j], g.v[j], g.scratch[j], g.M[j], g.K[j], eps, training, g.vs[j], sm, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void spectral_group_c_kernel(const SnGroup g, float* __restrict__ sigma, float eps, int training) {
+    __shared__ float red[32];
+    const int j = blockIdx.y;
+    spectral_c_body(g.w[j], g.u[j], g.scratch[j], g.wn[j], sigma + j, g.M[j], g.K[j], eps, training, g.us[j], red, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void spectral_group_bwd_a_kernel(const SnGroupBwd g) {
+    __shared__ float red[32];
+    const int j = blockIdx.y;
+    spectral_bwd_a_body(g.dwn[j], g.w[j], g.scratch[j], g.M[j], g.K[j], red, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void spectral_group_bwd_b_kernel(const SnGroupBwd g) {
+    const int j = blockIdx.y;
+    spectral_bwd_b_body(g.dwn[j], g.u[j], g.v[j], g.sigma[j], g.scratch[j], g.dw[j], g.M[j], g.K[j], g.accumulate[j], blockIdx.x);
 }
 
 }  // namespace mstg
@@ -289,5 +360,83 @@ extern "C" int mstg_spectral_norm_bwd(const float* dwn, const float* w, const fl
     }
     MSTG_LAUNCH(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dwn, w, u, v, sigma, dw, M, K, accumulate);
     MSTG_CHECK_LAUNCH("spectral_norm_bwd_kernel");
+    return MSTG_OK;
+}
+
+// ---- grouped entry points -------------------------------------------------------------------------------------------------------
+static size_t sn_group_floats(int M, int K) { return ((size_t)SN_G * K + M + SN_G + 16 + 3) & ~(size_t)3; }
+
+extern "C" int mstg_spectral_norm_group_max(void) { return SN_MAX_GROUP; }
+
+extern "C" size_t mstg_spectral_norm_group_workspace_bytes(int count, const int* M, const int* K) {
+    if (count <= 0 || count > SN_MAX_GROUP || !M || !K) return 0;
+    size_t n = 0;
+    for (int j = 0; j < count; ++j) {
+        if (M[j] <= 0 || K[j] <= 0) return 0;
+        n += sn_group_floats(M[j], K[j]);
+    }
+    return n * sizeof(float);
+}
+
+// w / u / v / w_out / u_save / v_save: `count` pointers each (u_save / v_save may be null as a whole: no backward follows);
+// sigma: `count` floats.  Per weight the semantics of mstg_spectral_norm_fwd.
+extern "C" int mstg_spectral_norm_group_fwd(int count, const float* const* w, float* const* u, float* const* v, float* const* w_out,
+                                            float* sigma, float* const* u_save, float* const* v_save, const int* M, const int* K, float eps,
+                                            int training, void* workspace, size_t workspace_bytes, void* stream) {
+    if (count <= 0 || count > SN_MAX_GROUP) return fail_arg(MSTG_E_BADARG, "spectral_norm_group: 1..8 weights per call");
+    if (!w || !u || !v || !w_out || !sigma || !M || !K) return fail_arg(MSTG_E_BADARG, "spectral_norm_group: null pointer");
+    if (!workspace || workspace_bytes < mstg_spectral_norm_group_workspace_bytes(count, M, K))
+        return fail_arg(MSTG_E_WORKSPACE, "spectral_norm_group: workspace too small");
+    SnGroup g{};
+    float* scratch = (float*)workspace;
+    int kmax = 0;
+    for (int j = 0; j < count; ++j) {
+        if (!w[j] || !u[j] || !v[j] || !w_out[j]) return fail_arg(MSTG_E_BADARG, "spectral_norm_group: null pointer");
+        if (M[j] <= 0 || K[j] <= 0 || M[j] > 4096 || K[j] > 16384) return fail_arg(MSTG_E_UNSUPPORTED, "spectral_norm_group: matrix larger than 4096 x 16384");
+        g.w[j] = w[j]; g.u[j] = u[j]; g.v[j] = v[j]; g.wn[j] = w_out[j];
+        g.us[j] = u_save ? u_save[j] : nullptr;
+        g.vs[j] = v_save ? v_save[j] : nullptr;
+        g.M[j] = M[j]; g.K[j] = K[j];
+        g.scratch[j] = scratch;
+        scratch += sn_group_floats(M[j], K[j]);
+        if (K[j] > kmax) kmax = K[j];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(SN_G, count);
+    if (training) {
+        MSTG_LAUNCH(spectral_group_a_kernel, grid, dim3(256), 0, st, g);
+        MSTG_CHECK_LAUNCH("spectral_group_a_kernel");
+    }
+    MSTG_LAUNCH(spectral_group_b_kernel, grid, dim3(256), (size_t)(kmax + 64) * sizeof(float), st, g, eps, training);
+    MSTG_CHECK_LAUNCH("spectral_group_b_kernel");
+    MSTG_LAUNCH(spectral_group_c_kernel, grid, dim3(256), 0, st, g, sigma, eps, training);
+    MSTG_CHECK_LAUNCH("spectral_group_c_kernel");
+    return MSTG_OK;
+}
+
+// dwn / w / u / v / sigma / dw: `count` pointers each (sigma[j] points at that weight's sigma); accumulate[j] != 0 adds into dw[j].
+extern "C" int mstg_spectral_norm_group_bwd(int count, const float* const* dwn, const float* const* w, const float* const* u,
+                                            const float* const* v, const float* const* sigma, float* const* dw, const int* accumulate,
+                                            const int* M, const int* K, void* workspace, size_t workspace_bytes, void* stream) {
+    if (count <= 0 || count > SN_MAX_GROUP) return fail_arg(MSTG_E_BADARG, "spectral_norm_group_bwd: 1..8 weights per call");
+    if (!dwn || !w || !u || !v || !sigma || !dw || !accumulate || !M || !K) return fail_arg(MSTG_E_BADARG, "spectral_norm_group_bwd: null pointer");
+    if (!workspace || workspace_bytes < mstg_spectral_norm_group_workspace_bytes(count, M, K))
+        return fail_arg(MSTG_E_WORKSPACE, "spectral_norm_group_bwd: workspace too small");
+    SnGroupBwd g{};
+    float* scratch = (float*)workspace;
+    for (int j = 0; j < count; ++j) {
+        if (!dwn[j] || !w[j] || !u[j] || !v[j] || !sigma[j] || !dw[j]) return fail_arg(MSTG_E_BADARG, "spectral_norm_group_bwd: null pointer");
+        if (M[j] <= 0 || K[j] <= 0) return fail_arg(MSTG_E_BADARG, "spectral_norm_group_bwd: bad shape");
+        g.dwn[j] = dwn[j]; g.w[j] = w[j]; g.u[j] = u[j]; g.v[j] = v[j]; g.sigma[j] = sigma[j]; g.dw[j] = dw[j];
+        g.M[j] = M[j]; g.K[j] = K[j]; g.accumulate[j] = accumulate[j];
+        g.scratch[j] = scratch;
+        scratch += sn_group_floats(M[j], K[j]);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(SN_G, count);
+    MSTG_LAUNCH(spectral_group_bwd_a_kernel, grid, dim3(256), 0, st, g);
+    MSTG_CHECK_LAUNCH("spectral_group_bwd_a_kernel");
+    MSTG_LAUNCH(spectral_group_bwd_b_kernel, grid, dim3(256), 0, st, g);
+    MSTG_CHECK_LAUNCH("spectral_group_bwd_b_kernel");
     return MSTG_OK;
 }

@@ -1214,12 +1214,106 @@ def install_fused_spectral_norm(module, name: str = "weight") -> bool:
             del module._forward_pre_hooks[key]
 
             def pre(mod, inputs, _eps=eps, _name=name):
+                if mod.__dict__.pop("_mstg_sn_fresh", False):
+                    return  # spectral_norm_group() has just normalised this weight (and run its power iteration) for this forward
                 setattr(mod, _name, SpectralNormFn.apply(getattr(mod, _name + "_orig"), getattr(mod, _name + "_u"),
                                                          getattr(mod, _name + "_v"), _eps, mod.training))
 
             module.register_forward_pre_hook(pre)
+            module._mstg_sn = (name, eps)
             return True
     return False
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _int_array(values):
+    return (C.c_int * len(values))(*[int(v) for v in values])
+
+
+class SpectralNormGroupFn(torch.autograd.Function):
+    """SpectralNormFn for several weights in one call (mstg_spectral_norm_group_*): apply(eps, training, n, w_0..w_{n-1}, u_0.., v_0..)
+    -> n normalised weights.  Three launches for the group instead of up to thirteen; in the backward the weights whose output
+    received a gradient go through two launches together."""
+
+    @staticmethod
+    def forward(ctx, eps, training, n, *tensors):
+        lib = _lib.load()
+        ws_, us_, vs_ = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        ws_ = [_req(w, "spectral_norm weight") for w in ws_]
+        Ms = [w.shape[0] for w in ws_]
+        Ks = [w.numel() // w.shape[0] for w in ws_]
+        for w, u, v, M, K in zip(ws_, us_, vs_, Ms, Ks):
+            _req(u, "spectral_norm u"), _req(v, "spectral_norm v")
+            if u.numel() != M or v.numel() != K:
+                raise RuntimeError(f"mstg_hip spectral_norm: u/v sizes {u.numel()}/{v.numel()} do not match weight {tuple(w.shape)}")
+        dev = ws_[0].device
+        outs = [torch.empty_like(w) for w in ws_]
+        sigma = torch.empty(n, dtype=torch.float32, device=dev)
+        need = any(ctx.needs_input_grad[3:3 + n])
+        u_sv = [torch.empty_like(u) for u in us_] if need else None
+        v_sv = [torch.empty_like(v) for v in vs_] if need else None
+        Ma, Ka = _int_array(Ms), _int_array(Ks)
+        ws = _ws(lib.mstg_spectral_norm_group_workspace_bytes(n, Ma, Ka), dev)
+        _lib.check(lib.mstg_spectral_norm_group_fwd(n, _ptr_array(ws_), _ptr_array(us_), _ptr_array(vs_), _ptr_array(outs), _p(sigma),
+                                                    _ptr_array(u_sv) if need else None, _ptr_array(v_sv) if need else None, Ma, Ka,
+                                                    float(eps), int(bool(training)), _p(ws), ws.numel() * 4, _stream()),
+                   "mstg_spectral_norm_group_fwd")
+        ctx.n, ctx.dims, ctx.prefs = n, (Ms, Ks), tuple(ws_)
+        ctx.set_materialize_grads(False)  # an output the loss never used stays None in backward: its weight gets no gradient
+        if need:
+            ctx.save_for_backward(sigma, *ws_, *u_sv, *v_sv)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dwns):
+        lib = _lib.load()
+        n = ctx.n
+        saved = ctx.saved_tensors
+        sigma, ws_, us_, vs_ = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n], saved[1 + 2 * n:1 + 3 * n]
+        Ms, Ks = ctx.dims
+        live = [j for j in range(n) if dwns[j] is not None and ctx.needs_input_grad[3 + j]]
+        grads = [None] * n
+        if live:
+            dws, accs, dwn_l = [], [], []
+            for j in live:
+                slot = _grad_slot(ctx.prefs[j])
+                dws.append(slot if slot is not None else torch.empty_like(ws_[j]))
+                accs.append(slot is not None)
+                dwn_l.append(_req(dwns[j], "spectral_norm grad_output"))
+                if slot is None:
+                    grads[j] = dws[-1]
+            Ma, Ka = _int_array([Ms[j] for j in live]), _int_array([Ks[j] for j in live])
+            sig_ptrs = (C.c_void_p * len(live))(*[sigma.data_ptr() + 4 * j for j in live])
+            ws = _ws(lib.mstg_spectral_norm_group_workspace_bytes(len(live), Ma, Ka), sigma.device)
+            _lib.check(lib.mstg_spectral_norm_group_bwd(len(live), _ptr_array(dwn_l), _ptr_array([ws_[j] for j in live]),
+                                                        _ptr_array([us_[j] for j in live]), _ptr_array([vs_[j] for j in live]), sig_ptrs,
+                                                        _ptr_array(dws), _int_array(accs), Ma, Ka, _p(ws), ws.numel() * 4, _stream()),
+                       "mstg_spectral_norm_group_bwd")
+        return (None, None, None, *grads, *([None] * (2 * n)))
+
+
+def spectral_norm_group(modules) -> None:
+    """Normalise the weights of `modules` (each carrying the hook of install_fused_spectral_norm) for the forward that follows, all
+    in one grouped call; the modules' own hooks then find their weight fresh and do nothing.  Same buffers, same power iteration
+    per training-mode forward, same gradients as the per-module hook (enhanced_generator.py:269-271)."""
+    lib = _lib.load()
+    cap = lib.mstg_spectral_norm_group_max()
+    mods = list(modules)
+    for k in range(0, len(mods), cap):
+        part = mods[k:k + cap]
+        names = [m._mstg_sn[0] for m in part]
+        eps = part[0]._mstg_sn[1]
+        if any(m._mstg_sn[1] != eps or m.training != part[0].training for m in part):
+            raise RuntimeError("mstg_hip spectral_norm_group: the modules of a group share eps and the training flag")
+        outs = SpectralNormGroupFn.apply(eps, part[0].training, len(part), *[getattr(m, nm + "_orig") for m, nm in zip(part, names)],
+                                         *[getattr(m, nm + "_u") for m, nm in zip(part, names)],
+                                         *[getattr(m, nm + "_v") for m, nm in zip(part, names)])
+        for m, nm, w in zip(part, names, outs):
+            setattr(m, nm, w)
+            m.__dict__["_mstg_sn_fresh"] = True
 
 
 # ----------------------------------------------------------------------------------------------------------

@@ -191,6 +191,48 @@ def test_spectral_norm_fused_vs_torch(shape):
         report(f"spectral_norm {shape} it{it} dweight_orig", rel_l2(dw, dw_ref), 1e-4)
 
 
+def test_spectral_norm_group_vs_single():
+    """The grouped call (one discriminator forward's seven weights in three launches) against the one-weight call on the same
+    weights and vectors: normalised weights, the in-place evolution of u / v over three training-mode calls and one eval-mode call,
+    and the gradients -- with one output left out of the loss (the discriminator update never uses the structure head), whose
+    weight must then get no gradient, and with gradients accumulated straight into .grad slots (ops.direct_param_grads)."""
+    from mstg_hip import ops
+    shapes = [(16, 3, 4, 4), (32, 16, 4, 4), (64, 32, 4, 4), (128, 64, 4, 4), (1, 128, 4, 4), (128, 128, 3, 3), (1, 128, 4, 4)]
+    n = len(shapes)
+    w0 = [rnd(sh, 300 + j, 0.2) for j, sh in enumerate(shapes)]
+    u0 = [F.normalize(rnd((sh[0],), 320 + j), dim=0, eps=1e-12) for j, sh in enumerate(shapes)]
+    v0 = [F.normalize(rnd((sh[1] * sh[2] * sh[3],), 340 + j), dim=0, eps=1e-12) for j, sh in enumerate(shapes)]
+    wa = [t.to(DEV).requires_grad_(True) for t in w0]
+    wb = [torch.nn.Parameter(t.to(DEV)) for t in w0]
+    ua, va = [t.to(DEV) for t in u0], [t.to(DEV) for t in v0]
+    ub, vb = [t.to(DEV) for t in u0], [t.to(DEV) for t in v0]
+    skip = n - 2  # this output takes no part in the loss
+    for it in range(4):
+        training = it < 3
+        gy = [rnd(sh, 360 + 10 * it + j).to(DEV) for j, sh in enumerate(shapes)]
+        single = [ops.SpectralNormFn.apply(wa[j], ua[j], va[j], 1e-12, training) for j in range(n)]
+        group = ops.SpectralNormGroupFn.apply(1e-12, training, n, *wb, *ub, *vb)
+        ga = torch.autograd.grad(sum((single[j] * gy[j]).sum() for j in range(n) if j != skip), wa, allow_unused=True)
+        gb = torch.autograd.grad(sum((group[j] * gy[j]).sum() for j in range(n) if j != skip), wb, allow_unused=True)
+        assert ga[skip] is None and gb[skip] is None
+        for j in range(n):
+            report(f"spectral group it{it} weight {shapes[j]}", rel_l2(group[j], single[j]), 2e-6)
+            report(f"spectral group it{it} u {shapes[j]}", rel_l2(ub[j], ua[j]), 2e-6)
+            report(f"spectral group it{it} v {shapes[j]}", rel_l2(vb[j], va[j]), 2e-6)
+            if j != skip:
+                report(f"spectral group it{it} dweight_orig {shapes[j]}", rel_l2(gb[j], ga[j]), 1e-5)
+    # gradients straight into .grad (accumulating): what the train step does
+    seeds = [rnd(sh, 500 + j).to(DEV) for j, sh in enumerate(shapes)]
+    for w_, s0 in zip(wb, seeds):
+        w_.grad = s0.clone()
+    gy = [rnd(sh, 600 + j).to(DEV) for j, sh in enumerate(shapes)]
+    ref = torch.autograd.grad(sum((o * g_).sum() for o, g_ in zip(ops.SpectralNormGroupFn.apply(1e-12, False, n, *wb, *ub, *vb), gy)), wb)
+    with ops.direct_param_grads():
+        sum((o * g_).sum() for o, g_ in zip(ops.SpectralNormGroupFn.apply(1e-12, False, n, *wb, *ub, *vb), gy)).backward()
+    for w_, s0, r in zip(wb, seeds, ref):
+        assert torch.equal(w_.grad, s0 + r)
+
+
 @pytest.mark.parametrize("N,H,W,ch", [(2, 16, 24, 16), (2, 21, 37, 16), (1, 32, 32, 32), (2, 9, 20, 64), (3, 40, 56, 16), (1, 16, 16, 8),
                                       (1, 8, 8, 128)])
 def test_conv_channel_slices_and_accumulate(N, H, W, ch):
