@@ -8,6 +8,7 @@
 // Reference sites replaced: nn.InstanceNorm2d + nn.ReLU/nn.LeakyReLU(0.2) (enhanced_generator.py:54-75,93-94,
 // 100-101,107-108,122-123,129-130,242-251,263-264), the residual `+ x` (:84), nn.BatchNorm2d (pretrain.py:69-89).
 #include "common.h"
+#include <stdlib.h>
 
 namespace mstg {
 
@@ -20,7 +21,9 @@ struct NormGeom {
 static NormGeom norm_geom(int N, int HW, int C) {
     NormGeom g;
     g.N = N; g.HW = HW; g.C = C;
-    int split = 1024 / (N > 0 ? N : 1);
+    int wgs = 1024;  // workgroups the streaming passes aim for
+    { const char* e = env_get(ENV_NORM_WGS); if (e && atoi(e) >= 64) wgs = atoi(e); }
+    int split = wgs / (N > 0 ? N : 1);
     if (split < 1) split = 1;
     const int maxsplit = cdiv(HW, 64);
     if (split > maxsplit) split = maxsplit;
@@ -123,11 +126,27 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         float t1 = 0.f, t2 = 0.f;
         if (batch != 2 && batch != 3) {
             const int nb = batch ? 0 : n, ne = batch ? g.N : n + 1;
-            for (int nn = nb; nn < ne; ++nn)
-                for (int s = 0; s < psplit; ++s) {  // psplit = g.split, or 1 when a producer's epilogue already summed the tensor
-                    t1 += partial[((size_t)nn * psplit + s) * 2 * C + c];
-                    t2 += partial[((size_t)nn * psplit + s) * 2 * C + C + c];
+            for (int nn = nb; nn < ne; ++nn) {  // psplit = g.split, or what a producer's epilogue left (1 .. 16 rows per image)
+                const float* pp = partial + (size_t)nn * psplit * 2 * C + c;
+                int s = 0;
+                for (; s + 8 <= psplit; s += 8) {  // sixteen loads in flight per trip (this prologue is a chain of L2 latencies
+                    float a[8], b[8];              // otherwise); the additions keep the order s = 0, 1, ...
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        a[k] = pp[(size_t)(s + k) * 2 * C];
+                        b[k] = pp[(size_t)(s + k) * 2 * C + C];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        t1 += a[k];
+                        t2 += b[k];
+                    }
                 }
+                for (; s < psplit; ++s) {
+                    t1 += pp[(size_t)s * 2 * C];
+                    t2 += pp[(size_t)s * 2 * C + C];
+                }
+            }
         }
         if (!BWD) {
             float mean, rstd;
@@ -248,9 +267,24 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
     const float cnt = (float)g.HW;
     for (int c = threadIdx.x; c < C; c += 256) {
         float t1 = 0.f, t2 = 0.f;
-        for (int s = 0; s < g.split; ++s) {
-            t1 += partial[((size_t)n * g.split + s) * 2 * C + c];
-            t2 += partial[((size_t)n * g.split + s) * 2 * C + C + c];
+        const float* pp = partial + (size_t)n * g.split * 2 * C + c;
+        int s = 0;
+        for (; s + 8 <= g.split; s += 8) {  // as in norm_apply_kernel: loads batched, order of the additions unchanged
+            float a[8], b[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = pp[(size_t)(s + k) * 2 * C];
+                b[k] = pp[(size_t)(s + k) * 2 * C + C];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                t1 += a[k];
+                t2 += b[k];
+            }
+        }
+        for (; s < g.split; ++s) {
+            t1 += pp[(size_t)s * 2 * C];
+            t2 += pp[(size_t)s * 2 * C + C];
         }
         const float K = x[(size_t)n * g.HW * C + c];
         const float e1 = t1 / cnt;
