@@ -119,6 +119,8 @@ int mstg_conv2d_wgrad_norm(const mstg_conv_desc* d, const float* x_raw, const fl
  * (mean, rstd) [N][Cout][2] of y, summed in the epilogue (same layout as mstg_norm_stats; sums of squares instead of pivoted
  * sums, combined in double).  Backward: mstg_conv2d_dgrad / _wgrad as for mstg_conv2d_fwd. */
 int mstg_conv2d_fwd_norm_supported(const mstg_conv_desc* d);
+/* 1 where the epilogue statistics also cost less than a statistics pass over the output (the callers' default routing) */
+int mstg_conv2d_fwd_stats_pays(const mstg_conv_desc* d);
 size_t mstg_conv2d_fwd_norm_workspace_bytes(const mstg_conv_desc* d);
 int mstg_conv2d_fwd_norm(const mstg_conv_desc* d, const float* x, const float* in_stats, const float* w, const float* bias, float* y,
                          float* out_stats, void* workspace, size_t workspace_bytes, void* stream);

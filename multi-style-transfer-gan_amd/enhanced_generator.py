@@ -105,8 +105,8 @@ class _Stage(nn.Sequential):
                 and os.environ.get("MSTG_NORM_ATTN", "1") != "0")
         stats = None
         if (fold and os.environ.get("MSTG_NORM_EPILOGUE", "1") != "0" and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
-                and conv.padding == (1, 1) and ops.conv_norm_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, 4, 2, 1, 1,
-                                                                      transposed)):
+                and conv.padding == (1, 1) and ops.conv_stats_pays(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, 4, 2, 1, 1,
+                                                                   transposed)):
             # the norm's statistics come out of the convolution's epilogue: no pass over the tensor for them
             x, stats = ops.conv2d_stats(x, conv.weight, conv.bias, 4, 2, 1, 1, transposed=transposed)
         else:

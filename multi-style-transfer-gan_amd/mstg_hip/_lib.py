@@ -65,6 +65,7 @@ SIGNATURES = {
     "mstg_conv2d_wgrad_norm_supported": (_i, [_dp]),
     "mstg_conv2d_wgrad_norm": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_conv2d_fwd_norm_supported": (_i, [_dp]),
+    "mstg_conv2d_fwd_stats_pays": (_i, [_dp]),
     "mstg_conv2d_fwd_norm_workspace_bytes": (_sz, [_dp]),
     "mstg_conv2d_fwd_norm": (_i, [_dp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _sz, _vp]),
     "mstg_window_attn_norm_fwd": (_i, [_fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _i, _i, _vp]),

@@ -1179,6 +1179,16 @@ extern "C" int mstg_conv2d_fwd_norm_supported(const mstg_conv_desc* d) {
     return p32_eligible(a) && !a.x_nchw && !a.y_nchw && a.Co != 1 ? 1 : 0;
 }
 
+// 1 where taking the output's statistics in the epilogue is cheaper than a statistics pass over the output (MSTG_BSUMS_ALL=1: wherever
+// mstg_conv2d_fwd_norm_supported)
+extern "C" int mstg_conv2d_fwd_stats_pays(const mstg_conv_desc* d) {
+    if (!mstg_conv2d_fwd_norm_supported(d)) return 0;
+    IGemmArgs a{};
+    fill_fwd_args(d, a);
+    const char* e = env_get(ENV_BSUMS_ALL);
+    return (e && e[0] == '1') || p32_stats_pays(a) ? 1 : 0;
+}
+
 extern "C" size_t mstg_conv2d_fwd_norm_workspace_bytes(const mstg_conv_desc* d) {
     if (check_desc(d)) return 0;
     IGemmArgs a{};

@@ -1056,6 +1056,14 @@ bool p32_bsums_pays(const IGemmArgs& g) {
     return g.Co <= 32 && p.npf <= 8;
 }
 
+// ... and the statistics epilogue of a forward launch: 20-25 % on the 12-register variants (32 -> 64 and 64 -> 32 channel 4x4 layers:
+// 88 and 120 us a launch at batch 64, against 35 and 60 us for the statistics pass over their output), a few per cent elsewhere.
+bool p32_stats_pays(const IGemmArgs& g) {
+    P32Plan p;
+    if (!p32_eligible(g) || g.x_nchw || g.y_nchw || g.Co == 1 || p32_plan(g, p)) return false;
+    return p.npf <= 8;
+}
+
 static int launch_p32_full(const IGemmArgs& g, const float* in_stats, float* out_stats, const float* aux, const float* aux_stats,
                            void* workspace, size_t workspace_bytes, hipStream_t st);
 

@@ -42,6 +42,7 @@ int launch_p32_norm(const IGemmArgs& a, const float* in_stats, float* out_stats,
 // input-gradient launch that also emits the reduction sums of the InstanceNorm + ReLU backward its output feeds (conv_p32.hip)
 bool p32_generic(const IGemmArgs& a);
 bool p32_bsums_pays(const IGemmArgs& a);
+bool p32_stats_pays(const IGemmArgs& a);
 int launch_p32_bsums(const IGemmArgs& a, const float* aux, const float* aux_stats, float* sums, void* workspace, size_t workspace_bytes,
                      hipStream_t st);
 const char* p32_kernel_name(const IGemmArgs& a);

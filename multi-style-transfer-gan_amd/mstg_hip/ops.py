@@ -425,6 +425,16 @@ def conv_norm_supported(N, H, W, Cin, Cout, k, stride, pad, dil, transposed) -> 
     return bool(_lib.load().mstg_conv2d_fwd_norm_supported(C.byref(d)))
 
 
+def conv_stats_pays(N, H, W, Cin, Cout, k, stride, pad, dil, transposed) -> bool:
+    """conv_norm_supported and the epilogue statistics are cheaper than a statistics pass over the output (not so for the 32 <-> 64
+    channel 4x4 layers, whose kernel variant has no registers to spare for the sums)."""
+    if not conv_norm_supported(N, H, W, Cin, Cout, k, stride, pad, dil, transposed):
+        return False
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, transposed)
+    d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil, transposed)
+    return bool(_lib.load().mstg_conv2d_fwd_stats_pays(C.byref(d)))
+
+
 class ConvStatsFn(torch.autograd.Function):
     """(y, stats) = conv(x, w) + b with stats[n][c] = (mean, rstd) of y taken in the convolution's epilogue (NHWC, no activation);
     optional in_stats: x is the raw tensor in front of InstanceNorm + ReLU and is normalised while staged (the caller owns that
