@@ -122,7 +122,7 @@ __host__ __device__ __forceinline__ unsigned magic_u32(unsigned d) { return 0xFF
 template <int NB>
 __device__ __forceinline__ void stage_window_batch(const float* __restrict__ img, float* __restrict__ lds, int total, int e0, int cols,
                                                    int nq, unsigned m_cols, unsigned m_nq, int y0, int x0, int H, int W, int ctot,
-                                                   int nq_valid, int ckp, int tid) {
+                                                   int nq_valid, int ckp, int tid, int rowpad) {
     f32x4 v[NB];
     int dst[NB];
     bool ok[NB];
@@ -136,7 +136,7 @@ __device__ __forceinline__ void stage_window_batch(const float* __restrict__ img
         ok[k] = e < total && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && q < nq_valid;
         const unsigned off = ok[k] ? (unsigned)(iy * W + ix) * (unsigned)ctot + 4u * q : 0u;
         v[k] = *reinterpret_cast<const f32x4*>(img + off);
-        dst[k] = e < total ? p * ckp + 4 * q : -1;
+        dst[k] = e < total ? p * ckp + 4 * q + r * rowpad : -1;
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k)
@@ -145,13 +145,13 @@ __device__ __forceinline__ void stage_window_batch(const float* __restrict__ img
 
 __device__ __forceinline__ void stage_window(const float* __restrict__ img, float* __restrict__ lds, int rows, int cols, int nq,
                                              unsigned m_cols, unsigned m_nq, int y0, int x0, int H, int W, int ctot, int nq_valid,
-                                             int ckp, int tid) {
+                                             int ckp, int tid, int rowpad = 0) {  // rowpad: extra floats between the rows of the LDS image
     const int total = rows * cols * nq;
     int e0 = 0;
     for (; e0 + 1024 < total; e0 += 2048)  // more than four elements per thread left: eight loads in flight
-        stage_window_batch<8>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid);
+        stage_window_batch<8>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid, rowpad);
     for (; e0 < total; e0 += 1024)
-        stage_window_batch<4>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid);
+        stage_window_batch<4>(img, lds, total, e0, cols, nq, m_cols, m_nq, y0, x0, H, W, ctot, nq_valid, ckp, tid, rowpad);
 }
 
 // Window of a tensor with at most 4 channels (any layout: sy / sx / sc = row / pixel / channel stride in floats),

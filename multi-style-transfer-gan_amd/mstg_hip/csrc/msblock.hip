@@ -545,6 +545,209 @@ __global__ __launch_bounds__(256) void ms_fwd4_kernel(const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same 4x4x1 forward with ONE BRANCH PER WAVE.  ms_fwd4_kernel gives every wave 64 pixels and all four branches: per
+// (tap, channel quad) it reads one 16-byte patch operand and one 16-byte filter operand per row set from LDS for four 8-cycle
+// MFMAs -- twice (CH = 16) the LDS bandwidth a CU has per MFMA cycle, which is what bounds it (profiles/r03: LDS 50 % busy, matrix
+// pipe 32 %).  Here a wave owns one branch for the whole 16 x 16 tile (four 64-pixel sets): the filter operand of a (tap, quad) is
+// read ONCE and used against four patch operands, 5 (CH = 16) or 6 (CH = 32) LDS reads per 16 / 32 MFMAs instead of 8 / 12, and
+// at CH = 32 the 4-row blocks carry no dead rows (the 16-row kernel multiplies 8 zero rows on every ring tap).  The 1x1 branch
+// is a ninth of a 3x3 branch's work, so the 16 (branch, pixel set) units of a tile are dealt 28 tap-sets to each wave (see the kernel).
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS layout.  ds_read_b128 serves a wave in four 16-lane groups -- lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same
+// + 32 -- over 64 four-byte banks.  A lane's patch operand sits at (row, column) = (lane >> 4, lane & 15) with 20 floats between
+// columns: columns {0-3, 12-15} and columns {4-11} fall on complementary halves of the 64 banks, so a group is conflict-free exactly
+// when the row stride is = 0 mod 64 floats -- 512, not the dense 480 (= 32 mod 64: every read two-way conflicted, as every
+// multi-scale kernel on the dense layout measures, SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  The filter operand has four
+// distinct addresses per group (output channel j = lane & 3), CH + 4 floats apart so that they fall on different banks.
+constexpr int M4B_ROW = 512;
+static_assert(M4B_ROW >= MS_PW * MS_CKP && M4B_ROW % 64 == 0, "padded patch row");
+
+template <int CH, int JB, int NS>
+struct Ms4bBranch {  // branch JB on NS consecutive 64-pixel sets (acc[0 .. NS-1]); pbase addresses the first set
+    static constexpr int C4 = CH / 4, RS = C4 / 4, ROW = M4B_ROW, SET = 4 * ROW, LDW = CH + 4;
+    static constexpr int NSTEP = (JB == 0 ? 1 : 9) * 4;  // (tap, channel quad) steps of this branch per 16-channel chunk
+    struct Ops {
+        f32x4 a[RS], b[NS];
+    };
+    template <int S>
+    static __device__ __forceinline__ void load(Ops& o, const float* __restrict__ wl, const float* __restrict__ patch, int pbase, int wbase) {
+        constexpr int T9 = S / 4, Q = S % 4;
+        constexpr int d = JB == 0 ? 0 : (1 << (JB - 1));
+        constexpr int oy = JB == 0 ? 0 : (T9 / 3 - 1) * d, ox = JB == 0 ? 0 : (T9 % 3 - 1) * d;
+        constexpr int t = JB == 0 ? 0 : 1 + 9 * (JB - 1) + T9;  // tap slot in the LDS filter
+#pragma unroll
+        for (int rs = 0; rs < RS; ++rs) o.a[rs] = *reinterpret_cast<const f32x4*>(&wl[wbase + (t * C4 + 4 * rs) * LDW + 4 * Q]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) o.b[s] = *reinterpret_cast<const f32x4*>(&patch[pbase + s * SET + oy * ROW + ox * MS_CKP + 4 * Q]);
+    }
+    // fewer than four accumulators in rotation (one set, CH = 16 / 32): consecutive products of one accumulator would wait for each
+    // other, so the odd channels of a quad go to a second accumulator (`alt`) that run() adds at the end
+    static constexpr bool SPLIT = NS * RS < 4;
+    static __device__ __forceinline__ void mma(f32x4 (*acc)[RS], f32x4 (*alt)[RS], const Ops& o) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs) {
+                    if (SPLIT && (e & 1)) alt[s][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(o.a[rs][e], o.b[s][e], alt[s][rs], 0, 0, 0);
+                    else acc[s][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(o.a[rs][e], o.b[s][e], acc[s][rs], 0, 0, 0);
+                }
+    }
+    // step S multiplies the operands in `cur` while step S + 1's are on their way into `nxt`; the scheduling barriers keep the reads
+    // in front of this step's products and the compiler from hoisting every later read as well (it otherwise fills 240 registers)
+    template <int S>
+    static __device__ __forceinline__ void steps(f32x4 (*acc)[RS], f32x4 (*alt)[RS], Ops& cur, Ops& nxt, const float* wl, const float* patch,
+                                                 int pbase, int wbase) {
+        if constexpr (S + 1 < NSTEP) load<S + 1>(nxt, wl, patch, pbase, wbase);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(acc, alt, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S + 1 < NSTEP) steps<S + 1>(acc, alt, nxt, cur, wl, patch, pbase, wbase);
+    }
+    static __device__ __forceinline__ void run(f32x4 (*acc)[RS], const float* wl, const float* patch, int pbase, int wbase) {
+        Ops o0, o1;
+        f32x4 alt[NS][RS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int rs = 0; rs < RS; ++rs) alt[s][rs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load<0>(o0, wl, patch, pbase, wbase);
+        steps<0>(acc, alt, o0, o1, wl, patch, pbase, wbase);
+        if (SPLIT) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs) acc[s][rs] += alt[s][rs];
+        }
+    }
+};
+
+// the filter in the LDS layout of ms_fwd4b_kernel, [28 taps][C4 co][CH + 4] (pad zero), then the CH concatenated biases: packed once
+// per weight update (the caller's pack cache), so that a workgroup stages it with a few 16-byte loads instead of gathering
+// 28 * C4 * CH scalars from the four PyTorch-layout tensors per tile
+template <int CH>
+__global__ void ms_pack_fwd4b_kernel(MsParamPtrs prm, float* __restrict__ wp) {
+    constexpr int C4 = CH / 4, LDW = CH + 4, TOTAL = 28 * C4 * LDW;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < TOTAL + CH; idx += gridDim.x * blockDim.x) {
+        if (idx >= TOTAL) {
+            const int co = idx - TOTAL;
+            wp[idx] = prm.b[co / C4][co % C4];
+            continue;
+        }
+        const int ci = idx % LDW, co = (idx / LDW) % C4, t = idx / (LDW * C4);
+        float v = 0.f;
+        if (ci < CH) v = t == 0 ? prm.w[0][co * CH + ci] : prm.w[1 + (t - 1) / 9][(co * CH + ci) * 9 + (t - 1) % 9];
+        wp[idx] = v;
+    }
+}
+
+// Persistent: a workgroup stages the filter once and walks tiles blockIdx.x, + gridDim.x, ...; the NEXT (tile, chunk)'s patch -- nine
+// 16-byte loads per thread -- is in flight in registers while the current one is multiplied, so the only exposed memory latency is
+// the first patch's.
+template <int CH>
+__global__ __launch_bounds__(256, 2) void ms_fwd4b_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+                                                          int N, int H, int W, int tiles_x, int tiles_y, int ntiles) {
+    constexpr int C4 = CH / 4, RS = C4 / 4, NCHK = CH / 16, NS = 4, LDW = CH + 4, NPF = M4_PH * MS_PW * 4 / 256;
+    static_assert(M4_PH * MS_PW * 4 == NPF * 256, "patch quads divide evenly over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                  // [M4_PH][M4B_ROW]   one 16-channel chunk of x at a time, rows padded (above)
+    float* wl = smem + M4_PH * M4B_ROW;                   // [28 taps][C4 co][LDW]   the whole filter, staged once
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t plane = (size_t)H * W;
+    for (int e = tid; e < 28 * C4 * LDW / 4; e += 256) reinterpret_cast<f32x4*>(wl)[e] = reinterpret_cast<const f32x4*>(wp)[e];
+    // this thread's NPF patch quads: (row, column, channel quad) -> LDS offset, offset inside the image, row / column for the bounds
+    int pdst[NPF], prel[NPF], prc[NPF];
+    const unsigned m_pw = magic_u32(MS_PW);
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int e = 256 * k + tid, pix = e >> 2, q = e & 3;
+        const int r = (int)__umulhi((unsigned)pix, m_pw), c = pix - r * MS_PW;
+        pdst[k] = r * M4B_ROW + c * MS_CKP + 4 * q;
+        prel[k] = (r * W + c) * CH + 4 * q;
+        prc[k] = (r << 16) | c;
+    }
+    f32x4 pv[NPF];
+    unsigned pok = 0;
+    auto fetch = [&](int tile, int chunk) {  // issue the loads of (tile, chunk)'s patch
+        const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int y0 = ty0 * M4_TH - 4, x0 = tx0 * 16 - 4;
+        const float* img = x + (size_t)n * plane * CH + 16 * chunk + ((ptrdiff_t)y0 * W + x0) * CH;
+        pok = 0;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int iy = y0 + (prc[k] >> 16), ix = x0 + (prc[k] & 0xffff);
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            pv[k] = *reinterpret_cast<const f32x4*>(ok ? img + prel[k] : x);
+            pok |= (ok ? 1u : 0u) << k;
+        }
+    };
+    // lane (block b, j): pixel row 4*set + b/4, column 4*(b%4) + j ; supplies the weights of output channel 4*rs + j of its branch
+    const int b = lane >> 2, j = lane & 3;
+    const int pcol = 4 * (b & 3) + j;
+    const int pbase = ((b >> 2) + 4) * M4B_ROW + (pcol + 4) * MS_CKP;
+    int tile = blockIdx.x;
+    if (tile < ntiles) fetch(tile, 0);
+    f32x4 acc[NS][RS];
+    for (int it = 0; tile < ntiles; ++it) {
+        // Work of a tile = (branch, 64-pixel set) units of 9, 9, 9 and 1 tap: roles 0..2 take a 3x3 branch on sets 0..2 plus the 1x1
+        // branch on one set; role 3 takes set 3 of all four branches.  28 tap-sets each (one branch per wave would be 36 / 36 / 36 / 4);
+        // the role rotates with the tile so that the wave re-reading the filter per set (role 3) is not always on the same SIMD.
+        const int role = __builtin_amdgcn_readfirstlane((wave + blockIdx.x + it) & 3);
+        // acc[k]'s (branch, set): roles 0..2: (role + 1, k) for k < 3, (0, role) for k = 3; role 3: (k + 1, 3) for k < 3, (0, 3)
+#pragma unroll 1
+        for (int chunk = 0; chunk < NCHK; ++chunk) {
+            __syncthreads();  // the previous chunk's products are done with the patch
+#pragma unroll
+            for (int k = 0; k < NPF; ++k)
+                *reinterpret_cast<f32x4*>(&patch[pdst[k]]) = ((pok >> k) & 1) ? pv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            if (chunk + 1 < NCHK) fetch(tile, chunk + 1);
+            else if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x, 0);
+            if (chunk == 0) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int br = k == 3 ? 0 : (role == 3 ? k + 1 : role + 1);
+                    const float* bias = wp + 28 * C4 * LDW + C4 * br;
+#pragma unroll
+                    for (int rs = 0; rs < RS; ++rs) acc[k][rs] = *reinterpret_cast<const f32x4*>(bias + 4 * rs);  // register r = channel 4 rs + r
+                }
+            }
+            const int wbase = j * LDW + 16 * chunk;
+            constexpr int SET = 4 * M4B_ROW;
+            if (role == 0) {
+                Ms4bBranch<CH, 1, 3>::run(acc, wl, patch, pbase, wbase);
+                Ms4bBranch<CH, 0, 1>::run(acc + 3, wl, patch, pbase, wbase);
+            } else if (role == 1) {
+                Ms4bBranch<CH, 2, 3>::run(acc, wl, patch, pbase, wbase);
+                Ms4bBranch<CH, 0, 1>::run(acc + 3, wl, patch, pbase + SET, wbase);
+            } else if (role == 2) {
+                Ms4bBranch<CH, 3, 3>::run(acc, wl, patch, pbase, wbase);
+                Ms4bBranch<CH, 0, 1>::run(acc + 3, wl, patch, pbase + 2 * SET, wbase);
+            } else {
+                Ms4bBranch<CH, 1, 1>::run(acc, wl, patch, pbase + 3 * SET, wbase);
+                Ms4bBranch<CH, 2, 1>::run(acc + 1, wl, patch, pbase + 3 * SET, wbase);
+                Ms4bBranch<CH, 3, 1>::run(acc + 2, wl, patch, pbase + 3 * SET, wbase);
+                Ms4bBranch<CH, 0, 1>::run(acc + 3, wl, patch, pbase + 3 * SET, wbase);
+            }
+        }
+        const int tx0 = tile % tiles_x, ty0 = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int gx = tx0 * 16 + pcol;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int br = k == 3 ? 0 : (role == 3 ? k + 1 : role + 1), set = role == 3 ? 3 : (k == 3 ? role : k);
+            const int gy = ty0 * M4_TH + 4 * set + (b >> 2);
+            if (gy < H && gx < W) {
+                float* p = y + (((size_t)n * H + gy) * W + gx) * CH + C4 * br;
+#pragma unroll
+                for (int rs = 0; rs < RS; ++rs) *reinterpret_cast<f32x4*>(p + 4 * rs) = acc[k][rs];
+            }
+        }
+        tile += gridDim.x;
+    }
+}
+
 struct MsGradPtrs {
     float* dw[4];
     float* db[4];
@@ -705,6 +908,17 @@ static int launch_ms_wgrad(const float* x, const float* dy, const MsGradPtrs& ou
     return MSTG_OK;
 }
 
+static int ms_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 template <int CH>
 static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N, int H, int W, void* ws, size_t ws_bytes, hipStream_t st) {
     typedef MsUnits<CH> G;
@@ -712,19 +926,34 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
         const char* e = env_get(ENV_MS_FWD4);
         bool aligned = true;
         for (int k = 0; k < 4; ++k) aligned = aligned && (reinterpret_cast<uintptr_t>(prm.b[k]) & 15) == 0;
-        const bool use4 = CH == 16 || (CH == 32 && e && e[0] == '2');
-        if (use4 && aligned && H >= 16 && !(e && e[0] == '0')) {  // measured 1.6x faster than the 16-row-tile kernel at CH = 16
+        // MSTG_MS_FWD4: unset / 3 = the branch-per-wave 4x4x1 kernel at CH = 16 and 32; 1 = the pixel-per-wave 4x4x1 kernel at CH = 16
+        // (round 2); 2 = that kernel at CH = 32 too; 0 = the 16-row-tile kernel everywhere
+        const bool use4b = CH <= 32 && (!e || e[0] == '3');
+        const bool use4 = !use4b && ((CH == 16 && !(e && e[0] == '0')) || (CH == 32 && e && e[0] == '2'));
+        if ((use4 || use4b) && aligned && H >= 16) {
             constexpr int C4K = (CH <= 32 ? CH : 16);
             const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, M4_TH);
-            const size_t lds = (size_t)(M4_PH * MS_PW * MS_CKP + 28 * (C4K / 4) * C4K) * sizeof(float);
+            const size_t lds = use4b ? (size_t)(M4_PH * M4B_ROW + 28 * (C4K / 4) * (C4K + 4)) * sizeof(float)
+                                     : (size_t)(M4_PH * MS_PW * MS_CKP + 28 * (C4K / 4) * C4K) * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
                 hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_fwd4_kernel<C4K>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (er == hipSuccess)
+                    er = hipFuncSetAttribute(reinterpret_cast<const void*>(&ms_fwd4b_kernel<C4K>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024);
                 if (er != hipSuccess) return fail_launch(er, "hipFuncSetAttribute(ms_fwd4)");
                 attr4 = true;
             }
-            MSTG_LAUNCH((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
+            if (use4b) {
+                constexpr int PACKED = 28 * (C4K / 4) * (C4K + 4) + C4K;
+                if (!ws || ws_bytes < (size_t)PACKED * sizeof(float)) return fail_arg(MSTG_E_WORKSPACE, "msblock_fwd: workspace too small");
+                MSTG_PACK_LAUNCH((ms_pack_fwd4b_kernel<C4K>), dim3(cdiv(PACKED, 256)), dim3(256), 0, st, prm, (float*)ws);
+                MSTG_CHECK_LAUNCH("ms_pack_fwd4b_kernel");
+                const int ntiles = N * tiles_x * tiles_y, slots = 2 * ms_cus();  // two workgroups fit a CU's LDS
+                MSTG_LAUNCH((ms_fwd4b_kernel<C4K>), dim3(ntiles < slots ? ntiles : slots), dim3(256), lds, st, x, (const float*)ws, y, N, H, W,
+                            tiles_x, tiles_y, ntiles);
+            } else MSTG_LAUNCH((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
             MSTG_CHECK_LAUNCH("ms_fwd4_kernel");
             return MSTG_OK;
         }

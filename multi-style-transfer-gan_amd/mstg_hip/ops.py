@@ -26,6 +26,7 @@ Tensor = torch.Tensor
 def refresh_env() -> None:
     """Make the library re-read the MSTG_* switches (it reads them once, at load).  Python-side switches are read per call."""
     _lib.load().mstg_env_refresh()
+    bump_pack_epoch()  # a switch may select another kernel, and with it another packed-filter format
 
 
 def _stream() -> int:
@@ -574,7 +575,8 @@ class MSBranchesFn(torch.autograd.Function):
         y = torch.empty((N, H, W, 4 * c4), dtype=torch.float32, device=x.device)
         lib = _lib.load()
         if os.environ.get("MSTG_MS_UNFUSED", "0") != "1" and bool(lib.mstg_msblock_fused_supported(ch)) and 4 * c4 == ch:
-            wsb, packed = _cached_ws(tuple(wb), "ms_fwd", (ch,), lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
+            # (H >= 16: smaller maps go to another kernel, which packs the filter differently)
+            wsb, packed = _cached_ws(tuple(wb), "ms_fwd", (ch, H >= 16), lib.mstg_msblock_fwd_workspace_bytes(ch), x.device)
             wb_ptrs = []
             for j in range(4):
                 wb_ptrs += [_p(ws[j]), _p(bs[j])]

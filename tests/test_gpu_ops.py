@@ -266,7 +266,7 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
         report(f"msbranches db{j + 1}", rel_l2(gg[5 + j], gr[5 + j]), 1e-4)
 
 
-@pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
+@pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=1", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
                                  "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0",
                                  "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1",
                                  "MSTG_ATTN_REG=0", "MSTG_ATTN_BIG32=1"])
