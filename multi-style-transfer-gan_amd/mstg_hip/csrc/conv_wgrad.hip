@@ -769,6 +769,8 @@ __global__ __launch_bounds__(256, 3) void wgrad7_kernel(const WGradArgs a) {
 // channels, NW = its share of the Ch/16 output fragments).  x and dy are read exactly once.
 // =====================================================================================================================
 // pixels per staged tile: about eight 16-byte loads per thread (32 pixels at 64 + 192 channels, 256 at 16 + 16)
+__host__ __device__ constexpr int w1x1_ld(int frags) { return (frags & 1) ? 16 * frags : 16 * frags + 16; }
+
 static int wgrad_1x1_tile(int Cg, int Ch) {
     int p1 = (2048 / ((Cg + Ch) >> 2)) & ~3;
     return p1 < 32 ? 32 : (p1 > 256 ? 256 : p1);
@@ -779,7 +781,9 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
                                                         long P, int Cg, int g_ctot, int g_coff, int Ch, int h_ctot, int h_coff,
                                                         int with_bias, int P1, const float* __restrict__ in_stats, int HW) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lda = 16 * MF + 4, NF = (Ch + 15) / 16, ldb = 16 * NF + 4;
+    // row strides = 16 mod 32 floats: the operand reads (4 bytes, lanes (i, g) -> row k0 + g, column 16 f + i; banks mod 32 over the two
+    // 32-lane halves) then put rows g and g + 1 on the two halves of the banks (+ 4 made every read a two-way conflict)
+    const int NF = (Ch + 15) / 16, lda = w1x1_ld(MF), ldb = w1x1_ld(NF);
     float* As = smem;             // [P1][lda]
     float* Bs = smem + P1 * lda;  // [P1][ldb]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -794,56 +798,86 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     const int ea = P1 * qa, eb = P1 * qb;          // float4 elements of the two tiles
     const unsigned m_qa = magic_u32(qa), m_qb = magic_u32(qb);
     float bsum = 0.f;
+    const bool bsplit = Ch <= 64 && (256 % Ch) == 0;  // bias gradient: 256 / Ch threads per channel, combined in a fixed order at the end
+    const int nbg = bsplit ? 256 / Ch : 1, bch = bsplit ? tid % Ch : tid, bgrp = bsplit ? tid / Ch : 0;
     const long ntiles = (P + P1 - 1) / P1;
     // Both tiles of the NEXT pixel run travel into registers behind the current run's MFMAs (ea + eb <= 2048 float4 elements:
     // wgrad_1x1_tile): element e of a thread is row pr, channel quad q of the x tile (e < ea) or of the dy tile.
     f32x4 v[8];
     unsigned okm = 0;
-    auto locate = [&](int e, bool& isa, int& pr, int& q) {
-        isa = e < ea;
-        const int eb_ = e - ea;
-        pr = isa ? (qa == 1 ? e : (int)__umulhi((unsigned)e, m_qa)) : (qb == 1 ? eb_ : (int)__umulhi((unsigned)(eb_ < 0 ? 0 : eb_), m_qb));
-        q = isa ? e - pr * qa : eb_ - pr * qb;
-    };
+    // in_stats: (mean, rstd) of this thread's channel quad of the tile's image travel with the tile (256 is a multiple of the quads per
+    // pixel, so every x element of a thread has the same quad): two 16-byte loads per tile instead of eight scalar loads per element
+    f32x4 st_lo = {0.f, 1.f, 0.f, 1.f}, st_hi = {0.f, 1.f, 0.f, 1.f};
+    const bool st_fast = in_stats && (256 % qa) == 0;
+    // where this thread's eight elements live: tile-invariant, so the divisions happen once (they were a quarter of the kernel's
+    // instruction stream when redone per tile in both the fetch and the commit)
+    int dst8[8], pr8[8];
+    unsigned rel8[8], isa_m = 0, use_m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = 256 * k + tid;
+        const bool isa = e < ea, use = e < ea + eb;
+        const int eb_ = isa ? 0 : e - ea;
+        const int pr = isa ? (qa == 1 ? e : (int)__umulhi((unsigned)e, m_qa)) : (qb == 1 ? eb_ : (int)__umulhi((unsigned)eb_, m_qb));
+        const int q = isa ? e - pr * qa : eb_ - pr * qb;
+        pr8[k] = use ? pr : 0;
+        dst8[k] = isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q;
+        rel8[k] = use ? (isa ? (unsigned)pr * g_ctot + g_coff + 4 * q : (unsigned)pr * h_ctot + h_coff + 4 * q) : 0u;
+        isa_m |= (unsigned)isa << k;
+        use_m |= (unsigned)use << k;
+    }
     auto fetch = [&](long tile) {
         const long p0 = tile * P1;
+        const float* xa = x + (size_t)p0 * g_ctot;
+        const float* yb = dy + (size_t)p0 * h_ctot;
         okm = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int e = 256 * k + tid;
-            bool isa; int pr, q;
-            locate(e, isa, pr, q);
-            const bool ok = e < ea + eb && p0 + pr < P;
+            const bool ok = ((use_m >> k) & 1) && p0 + pr8[k] < P;
             okm |= (unsigned)ok << k;
-            const float* src = isa ? x + (size_t)(p0 + (ok ? pr : 0)) * g_ctot + g_coff + 4 * q
-                                   : dy + (size_t)(p0 + (ok ? pr : 0)) * h_ctot + h_coff + 4 * (ok ? q : 0);
-            v[k] = *reinterpret_cast<const f32x4*>(e < ea + eb ? src : x);
+            v[k] = *reinterpret_cast<const f32x4*>(ok ? (((isa_m >> k) & 1) ? xa : yb) + rel8[k] : x);
+        }
+        if (st_fast) {
+            const float* st = in_stats + ((size_t)(p0 / HW) * g_ctot + g_coff + 4 * (tid % qa)) * 2;
+            st_lo = *reinterpret_cast<const f32x4*>(st);
+            st_hi = *reinterpret_cast<const f32x4*>(st + 4);
         }
     };
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int e = 256 * k + tid;
-            if (e < ea + eb) {
-                bool isa; int pr, q;
-                locate(e, isa, pr, q);
+            if ((use_m >> k) & 1) {
+                const bool isa = (isa_m >> k) & 1;
                 f32x4 w = ((okm >> k) & 1) ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
                 if (in_stats && isa && ((okm >> k) & 1)) {
                     // x is the RAW tensor in front of InstanceNorm + ReLU: normalise here, as norm_apply_kernel would have (the host
                     // guarantees that a pixel run stays inside one image: HW % P1 == 0)
-                    const float* st = in_stats + ((size_t)(tile * P1 / HW) * g_ctot + g_coff + 4 * q) * 2;
+                    if (st_fast) {
+                        w[0] = fmaxf((w[0] - st_lo[0]) * st_lo[1], 0.f);
+                        w[1] = fmaxf((w[1] - st_lo[2]) * st_lo[3], 0.f);
+                        w[2] = fmaxf((w[2] - st_hi[0]) * st_hi[1], 0.f);
+                        w[3] = fmaxf((w[3] - st_hi[2]) * st_hi[3], 0.f);
+                    } else {
+                        const int q = (256 * k + tid) % qa;
+                        const float* st = in_stats + ((size_t)(tile * P1 / HW) * g_ctot + g_coff + 4 * q) * 2;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) w[c] = fmaxf((w[c] - st[2 * c]) * st[2 * c + 1], 0.f);
+                        for (int c = 0; c < 4; ++c) w[c] = fmaxf((w[c] - st[2 * c]) * st[2 * c + 1], 0.f);
+                    }
                 }
-                *reinterpret_cast<f32x4*>(&smem[isa ? pr * lda + 4 * q : P1 * lda + pr * ldb + 4 * q]) = w;
+                *reinterpret_cast<f32x4*>(&smem[dst8[k]]) = w;
             }
         }
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
-        if (with_bias && tid < Ch) {
+        if (with_bias) {  // column sums of the dy tile: every thread takes the pixels p = bgrp, bgrp + nbg, ... of channel bch
+            if (bsplit) {
+#pragma unroll 4
+                for (int p = bgrp; p < P1; p += nbg) bsum += Bs[p * ldb + bch];
+            } else if (tid < Ch) {
 #pragma unroll 8
-            for (int p = 0; p < P1; ++p) bsum += Bs[p * ldb + tid];
+                for (int p = 0; p < P1; ++p) bsum += Bs[p * ldb + tid];
+            }
         }
         // ---- MFMA: K = the tile's 32 pixels, 4 per step ---------------------------------------------------------------------------
 #pragma unroll 2
@@ -882,6 +916,18 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
     // partial slab [Cg][Ch] (+ [Ch] bias tail), the layout wgrad_reduce_kernel expects for T = 1
     const size_t pstride = (size_t)Cg * Ch + (with_bias ? Ch : 0);
     float* out = partial + (size_t)blockIdx.x * pstride;
+    if (with_bias && bsplit) {  // groups 0, 1, ... of a channel, in that order
+        __syncthreads();
+        float* red = smem;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < Ch) {
+            float t = 0.f;
+            for (int k = 0; k < nbg; ++k) t += red[k * Ch + tid];
+            bsum = t;
+        }
+        __syncthreads();
+    }
     if (with_bias && tid < Ch) out[(size_t)Cg * Ch + tid] = bsum;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -901,7 +947,7 @@ __global__ __launch_bounds__(256) void wgrad_1x1_kernel(const float* __restrict_
 template <int MF, int NW>
 static int launch_wgrad_1x1(const WGradArgs& a, long P, int S, hipStream_t st, const float* in_stats = nullptr) {
     const int NF = cdiv(a.Ch, 16), P1 = wgrad_1x1_tile(a.Cg, a.Ch);
-    const size_t lds = (size_t)P1 * ((16 * MF + 4) + (16 * NF + 4)) * sizeof(float);
+    const size_t lds = (size_t)P1 * (w1x1_ld(MF) + w1x1_ld(NF)) * sizeof(float);
     MSTG_LAUNCH((wgrad_1x1_kernel<MF, NW>), dim3(S), dim3(256), lds, st, a.g, a.h, a.partial, P, a.Cg, a.g_ctot, a.g_coff, a.Ch,
                        a.h_ctot, a.h_coff, a.with_bias, P1, in_stats, a.hH * a.hW);
     MSTG_CHECK_LAUNCH("wgrad_1x1_kernel");
