@@ -375,10 +375,28 @@ __global__ __launch_bounds__(256) void p32_norm_finalize_kernel(const float* __r
     // rows written for image n: the workgroups whose contiguous tile range [b * chunk, (b + 1) * chunk) meets the image's tiles
     const int b_lo = (int)(((long)n * ntile) / chunk), b_hi = (int)((((long)n + 1) * ntile - 1) / chunk);
     double s1 = 0.0, s2 = 0.0;
-    for (int b = b_lo + sub; b <= b_hi && b < G; b += per_c) {
-        const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
-        s1 += (double)pp[c];
-        s2 += (double)pp[CP + c];
+    {   // eight rows' loads in flight per trip (at batch 1 an image has hundreds of rows); the additions keep their order
+        const int b_end = (b_hi < G - 1 ? b_hi : G - 1) + 1;
+        int b = b_lo + sub;
+        for (; b + 7 * per_c < b_end; b += 8 * per_c) {
+            float u[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pp = partial + ((size_t)n * G + b + k * per_c) * 2 * CP;
+                u[k] = pp[c];
+                w[k] = pp[CP + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s1 += (double)u[k];
+                s2 += (double)w[k];
+            }
+        }
+        for (; b < b_end; b += per_c) {
+            const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
+            s1 += (double)pp[c];
+            s2 += (double)pp[CP + c];
+        }
     }
     red[tid * 2] = s1;
     red[tid * 2 + 1] = s2;
@@ -402,10 +420,28 @@ __global__ __launch_bounds__(256) void p32_bsum_finalize_kernel(const float* __r
     const int per_c = 256 / CP, c = tid % CP, sub = tid / CP;
     const int b_lo = (int)(((long)n * ntile) / chunk), b_hi = (int)((((long)n + 1) * ntile - 1) / chunk);
     double s1 = 0.0, s2 = 0.0;
-    for (int b = b_lo + sub; b <= b_hi && b < G; b += per_c) {
-        const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
-        s1 += (double)pp[c];
-        s2 += (double)pp[CP + c];
+    {   // eight rows' loads in flight per trip (at batch 1 an image has hundreds of rows); the additions keep their order
+        const int b_end = (b_hi < G - 1 ? b_hi : G - 1) + 1;
+        int b = b_lo + sub;
+        for (; b + 7 * per_c < b_end; b += 8 * per_c) {
+            float u[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pp = partial + ((size_t)n * G + b + k * per_c) * 2 * CP;
+                u[k] = pp[c];
+                w[k] = pp[CP + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s1 += (double)u[k];
+                s2 += (double)w[k];
+            }
+        }
+        for (; b < b_end; b += per_c) {
+            const float* pp = partial + ((size_t)n * G + b) * 2 * CP;
+            s1 += (double)pp[c];
+            s2 += (double)pp[CP + c];
+        }
     }
     red[tid * 2] = s1;
     red[tid * 2 + 1] = s2;

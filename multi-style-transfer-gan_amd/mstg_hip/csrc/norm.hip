@@ -25,7 +25,7 @@ static NormGeom norm_geom(int N, int HW, int C) {
     { const char* e = env_get(ENV_NORM_WGS); if (e && atoi(e) >= 64) wgs = atoi(e); }
     int split = wgs / (N > 0 ? N : 1);
     if (split < 1) split = 1;
-    const int maxsplit = cdiv(HW, 64);
+    const int maxsplit = cdiv(HW, 256);  // >= 256 pixels per workgroup (batch 1-2 at 256 x 256: 256 rows per image, not 1024)
     if (split > maxsplit) split = maxsplit;
     g.chunk = cdiv(HW, split);
     g.split = cdiv(HW, g.chunk);
@@ -260,21 +260,22 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
     }
 }
 
-// (mean, rstd) per (image, channel) from the pivoted partial sums: the arithmetic of norm_apply_kernel<false>, bit for bit
-__global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict__ x, const float* __restrict__ partial,
-                                                         float* __restrict__ stats, NormGeom g) {
-    const int n = blockIdx.x, C = g.C;
-    const float cnt = (float)g.HW;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float t1 = 0.f, t2 = 0.f;
-        const float* pp = partial + (size_t)n * g.split * 2 * C + c;
-        int s = 0;
-        for (; s + 8 <= g.split; s += 8) {  // as in norm_apply_kernel: loads batched, order of the additions unchanged
+// Sum of an image's `split` partial rows per channel, t1 / t2, in a fixed order.  groups == 1: s = 0, 1, ... (the order of
+// norm_apply_kernel's own prologue, bit for bit); groups > 1 (small batches: up to 1024 rows per image): thread group k takes rows
+// k, k + groups, ..., the groups are added 0, 1, ... through LDS.  Loads are batched eight rows at a time.
+__device__ __forceinline__ void norm_row_sums(const float* __restrict__ partial, int n, int split, int C, int groups, float* red, float& t1,
+                                              float& t2) {
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C;
+    t1 = t2 = 0.f;
+    if (grp < groups) {
+        const float* pp = partial + (size_t)n * split * 2 * C + c;
+        int s = grp;
+        for (; s + 7 * groups < split; s += 8 * groups) {
             float a[8], b[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                a[k] = pp[(size_t)(s + k) * 2 * C];
-                b[k] = pp[(size_t)(s + k) * 2 * C + C];
+                a[k] = pp[(size_t)(s + k * groups) * 2 * C];
+                b[k] = pp[(size_t)(s + k * groups) * 2 * C + C];
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -282,16 +283,59 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(const float* __restrict
                 t2 += b[k];
             }
         }
-        for (; s < g.split; ++s) {
+        for (; s < split; s += groups) {
             t1 += pp[(size_t)s * 2 * C];
             t2 += pp[(size_t)s * 2 * C + C];
         }
+    }
+    if (groups > 1) {
+        if (grp < groups) {
+            red[(grp * 2 + 0) * C + c] = t1;
+            red[(grp * 2 + 1) * C + c] = t2;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            t1 = t2 = 0.f;
+            for (int k = 0; k < groups; ++k) {
+                t1 += red[(k * 2 + 0) * C + c];
+                t2 += red[(k * 2 + 1) * C + c];
+            }
+        }
+    }
+}
+
+// threads per workgroup of the two kernels below: C channels x `groups` row groups (C <= 1024)
+static int norm_groups(const NormGeom& g) { return g.split > 32 && g.C <= 128 ? 256 / g.C : 1; }
+static int norm_row_threads(const NormGeom& g) { const int t = g.C * norm_groups(g); return t < 64 ? 64 : ((t + 63) / 64) * 64; }
+
+// (mean, rstd) per (image, channel) from the pivoted partial sums: the arithmetic of norm_apply_kernel<false>
+__global__ void norm_stats_kernel(const float* __restrict__ x, const float* __restrict__ partial, float* __restrict__ stats, NormGeom g,
+                                  int groups) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int n = blockIdx.x, C = g.C;
+    const float cnt = (float)g.HW;
+    float t1, t2;
+    norm_row_sums(partial, n, g.split, C, groups, red, t1, t2);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
         const float K = x[(size_t)n * g.HW * C + c];
         const float e1 = t1 / cnt;
         float var = t2 / cnt - e1 * e1;
         var = var > 0.f ? var : 0.f;
         stats[((size_t)n * C + c) * 2] = K + e1;
         stats[((size_t)n * C + c) * 2 + 1] = rsqrtf(var + NORM_EPS);
+    }
+}
+
+// backward: sums[n][2][C] = the image's two reductions, for norm_apply_kernel<true> with one row per image
+__global__ void norm_sums_kernel(const float* __restrict__ partial, float* __restrict__ sums, NormGeom g, int groups) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int n = blockIdx.x, C = g.C;
+    float t1, t2;
+    norm_row_sums(partial, n, g.split, C, groups, red, t1, t2);
+    if ((int)threadIdx.x < C) {
+        sums[((size_t)n * 2 + 0) * C + threadIdx.x] = t1;
+        sums[((size_t)n * 2 + 1) * C + threadIdx.x] = t2;
     }
 }
 
@@ -308,7 +352,7 @@ using namespace mstg;
 extern "C" size_t mstg_norm_workspace_bytes(int N, int HW, int C) {
     if (N <= 0 || HW <= 0 || C <= 0) return 0;
     const NormGeom g = norm_geom(N, HW, C);
-    return (size_t)N * g.split * 2 * C * sizeof(float);
+    return ((size_t)N * g.split * 2 * C + (size_t)N * 2 * C) * sizeof(float);  // partial rows + one summed row per image
 }
 
 extern "C" int mstg_norm_act_fwd(const float* x, const float* residual, float* y, float* stats, int N, int HW, int C, int act,
@@ -327,6 +371,18 @@ extern "C" int mstg_norm_act_fwd(const float* x, const float* residual, float* y
         MSTG_LAUNCH((norm_partial_kernel<false>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr, nullptr,
                            gamma, beta, (float*)workspace, g, act, batch_stats);
         MSTG_CHECK_LAUNCH("norm_partial_kernel");
+    }
+    if (batch_stats == 0 && g.split > 32) {
+        // small batch: an image has up to 1024 partial rows, and EVERY apply workgroup would re-add them in its prologue (at batch 1
+        // that prologue was the whole kernel): one statistics launch, then the apply pass with the statistics given
+        const int groups = norm_groups(g);
+        MSTG_LAUNCH(norm_stats_kernel, dim3(N), dim3(norm_row_threads(g)), (size_t)groups * 2 * C * sizeof(float), st, x,
+                    (const float*)workspace, stats, g, groups);
+        MSTG_CHECK_LAUNCH("norm_stats_kernel");
+        MSTG_LAUNCH((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, g, act, 3, 0);
+        MSTG_CHECK_LAUNCH("norm_apply_kernel");
+        return MSTG_OK;
     }
     MSTG_LAUNCH((norm_apply_kernel<false>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, nullptr, residual, y, stats,
                        gamma, beta, running_mean, running_var, nullptr, nullptr, (const float*)workspace, g, act, batch_stats, g.split);
@@ -349,6 +405,17 @@ extern "C" int mstg_norm_act_bwd(const float* x, const float* stats, const float
     MSTG_LAUNCH((norm_partial_kernel<true>), grid, dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, dy, stats, gamma, beta,
                        (float*)workspace, g, act, batch_stats);
     MSTG_CHECK_LAUNCH("norm_partial_kernel<bwd>");
+    if (batch_stats == 0 && g.split > 32) {  // as in the forward: the rows are added once, not by every apply workgroup
+        const int groups = norm_groups(g);
+        float* sums = (float*)workspace + (size_t)N * g.split * 2 * C;
+        MSTG_LAUNCH(norm_sums_kernel, dim3(N), dim3(norm_row_threads(g)), (size_t)groups * 2 * C * sizeof(float), st, (const float*)workspace,
+                    sums, g, groups);
+        MSTG_CHECK_LAUNCH("norm_sums_kernel");
+        MSTG_LAUNCH((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx, const_cast<float*>(stats),
+                    gamma, beta, nullptr, nullptr, dgamma, dbeta, (const float*)sums, g, act, batch_stats, 1);
+        MSTG_CHECK_LAUNCH("norm_apply_kernel<bwd>");
+        return MSTG_OK;
+    }
     MSTG_LAUNCH((norm_apply_kernel<true>), grid, dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, nullptr, dx,
                        const_cast<float*>(stats), gamma, beta, nullptr, nullptr, dgamma, dbeta, (const float*)workspace, g, act,
                        batch_stats, g.split);
@@ -369,7 +436,9 @@ extern "C" int mstg_norm_stats(const float* x, float* stats, int N, int HW, int 
     MSTG_LAUNCH((norm_partial_kernel<false>), dim3(g.split, N), dim3(256), (size_t)rows * 2 * C * sizeof(float), st, x, nullptr,
                        nullptr, nullptr, nullptr, (float*)workspace, g, MSTG_ACT_NONE, 0);
     MSTG_CHECK_LAUNCH("norm_partial_kernel");
-    MSTG_LAUNCH(norm_stats_kernel, dim3(N), dim3(256), 0, st, x, (const float*)workspace, stats, g);
+    const int groups = norm_groups(g);
+    MSTG_LAUNCH(norm_stats_kernel, dim3(N), dim3(norm_row_threads(g)), (size_t)groups * 2 * C * sizeof(float), st, x, (const float*)workspace,
+                stats, g, groups);
     MSTG_CHECK_LAUNCH("norm_stats_kernel");
     return MSTG_OK;
 }
