@@ -681,10 +681,27 @@ __global__ __launch_bounds__(256) void f16_norm_finalize_kernel(const float* __r
     const int lanes_per_c = 256 / CP;            // CP in {16, 32, 64} -> 16 / 8 / 4 threads share a channel
     const int c = tid % CP, sub = tid / CP;
     double s1 = 0.0, s2 = 0.0;
-    for (int tl = sub; tl < tiles; tl += lanes_per_c) {
-        const float* pp = partial + ((size_t)n * tiles + tl) * 2 * CP;
-        s1 += (double)pp[c];
-        s2 += (double)pp[CP + c];
+    {   // an image has thousands of tile rows at 1024 x 1024: sixteen loads in flight per trip, the additions in their old order
+        int tl = sub;
+        for (; tl + 7 * lanes_per_c < tiles; tl += 8 * lanes_per_c) {
+            float u[8], w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float* pp = partial + ((size_t)n * tiles + tl + k * lanes_per_c) * 2 * CP;
+                u[k] = pp[c];
+                w[k] = pp[CP + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                s1 += (double)u[k];
+                s2 += (double)w[k];
+            }
+        }
+        for (; tl < tiles; tl += lanes_per_c) {
+            const float* pp = partial + ((size_t)n * tiles + tl) * 2 * CP;
+            s1 += (double)pp[c];
+            s2 += (double)pp[CP + c];
+        }
     }
     red[tid * 2] = s1;
     red[tid * 2 + 1] = s2;
