@@ -581,46 +581,31 @@ struct Ms4bBranch {  // branch JB on NS consecutive 64-pixel sets (acc[0 .. NS-1
 #pragma unroll
         for (int s = 0; s < NS; ++s) o.b[s] = *reinterpret_cast<const f32x4*>(&patch[pbase + s * SET + oy * ROW + ox * MS_CKP + 4 * Q]);
     }
-    // fewer than four accumulators in rotation (one set, CH = 16 / 32): consecutive products of one accumulator would wait for each
-    // other, so the odd channels of a quad go to a second accumulator (`alt`) that run() adds at the end
-    static constexpr bool SPLIT = NS * RS < 4;
-    static __device__ __forceinline__ void mma(f32x4 (*acc)[RS], f32x4 (*alt)[RS], const Ops& o) {
+    // one accumulator per (set, row set), products added in the order tap, channel: the summation order of ms_fwd4_kernel, bit for bit
+    // (splitting the chain over two accumulators to shorten the dependency bought nothing: the 8-cycle products of the other sets and
+    // the operand reads fill the gaps)
+    static __device__ __forceinline__ void mma(f32x4 (*acc)[RS], const Ops& o) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
-                for (int rs = 0; rs < RS; ++rs) {
-                    if (SPLIT && (e & 1)) alt[s][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(o.a[rs][e], o.b[s][e], alt[s][rs], 0, 0, 0);
-                    else acc[s][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(o.a[rs][e], o.b[s][e], acc[s][rs], 0, 0, 0);
-                }
+                for (int rs = 0; rs < RS; ++rs) acc[s][rs] = __builtin_amdgcn_mfma_f32_4x4x1f32(o.a[rs][e], o.b[s][e], acc[s][rs], 0, 0, 0);
     }
     // step S multiplies the operands in `cur` while step S + 1's are on their way into `nxt`; the scheduling barriers keep the reads
     // in front of this step's products and the compiler from hoisting every later read as well (it otherwise fills 240 registers)
     template <int S>
-    static __device__ __forceinline__ void steps(f32x4 (*acc)[RS], f32x4 (*alt)[RS], Ops& cur, Ops& nxt, const float* wl, const float* patch,
-                                                 int pbase, int wbase) {
+    static __device__ __forceinline__ void steps(f32x4 (*acc)[RS], Ops& cur, Ops& nxt, const float* wl, const float* patch, int pbase, int wbase) {
         if constexpr (S + 1 < NSTEP) load<S + 1>(nxt, wl, patch, pbase, wbase);
         __builtin_amdgcn_sched_barrier(0);
-        mma(acc, alt, cur);
+        mma(acc, cur);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S + 1 < NSTEP) steps<S + 1>(acc, alt, nxt, cur, wl, patch, pbase, wbase);
+        if constexpr (S + 1 < NSTEP) steps<S + 1>(acc, nxt, cur, wl, patch, pbase, wbase);
     }
     static __device__ __forceinline__ void run(f32x4 (*acc)[RS], const float* wl, const float* patch, int pbase, int wbase) {
         Ops o0, o1;
-        f32x4 alt[NS][RS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int rs = 0; rs < RS; ++rs) alt[s][rs] = f32x4{0.f, 0.f, 0.f, 0.f};
         load<0>(o0, wl, patch, pbase, wbase);
-        steps<0>(acc, alt, o0, o1, wl, patch, pbase, wbase);
-        if (SPLIT) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int rs = 0; rs < RS; ++rs) acc[s][rs] += alt[s][rs];
-        }
+        steps<0>(acc, o0, o1, wl, patch, pbase, wbase);
     }
 };
 
