@@ -150,6 +150,10 @@ def load() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -m mstg_hip.build` (or __graft_entry__.build()). "
                 "This package has no CPU or eager-PyTorch fallback.")
+        # torch first: it ships its own libamdhip64 / libhsa-runtime64, and this library must bind to THAT runtime (the one that owns
+        # torch's device memory and streams).  Loaded before torch, this library pulls in /opt/rocm's copy, the process then holds two
+        # HIP runtimes and every launch from here fails with "no ROCm-capable device is detected".
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
