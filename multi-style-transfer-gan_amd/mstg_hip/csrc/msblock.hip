@@ -555,17 +555,30 @@ __global__ __launch_bounds__(256) void ms_fwd4_kernel(const float* __restrict__ 
 // is a ninth of a 3x3 branch's work, so the 16 (branch, pixel set) units of a tile are dealt 28 tap-sets to each wave (see the kernel).
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS layout.  ds_read_b128 serves a wave in four 16-lane groups -- lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same
-// + 32 -- over 64 four-byte banks.  A lane's patch operand sits at (row, column) = (lane >> 4, lane & 15) with 20 floats between
-// columns: columns {0-3, 12-15} and columns {4-11} fall on complementary halves of the 64 banks, so a group is conflict-free exactly
-// when the row stride is = 0 mod 64 floats -- 512, not the dense 480 (= 32 mod 64: every read two-way conflicted, as every
-// multi-scale kernel on the dense layout measures, SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE).  The filter operand has four
-// distinct addresses per group (output channel j = lane & 3), CH + 4 floats apart so that they fall on different banks.
-constexpr int M4B_ROW = 512;
-static_assert(M4B_ROW >= MS_PW * MS_CKP && M4B_ROW % 64 == 0, "padded patch row");
+// + 32 -- over 64 four-byte banks.  With 20 floats between pixel columns, 16 consecutive columns of ONE patch row fall on 16 different
+// 4-bank slots; two different rows collide unless the row stride is 0 mod 64 floats (the dense 480 is 32 mod 64: with lanes mapped
+// (row, column) = (lane >> 4, lane & 15) every read of every multi-scale kernel is a two-way conflict, SQ_LDS_BANK_CONFLICT = half of
+// SQ_LDS_IDX_ACTIVE).  The 4x4x1 MFMA does not care which pixel a lane holds (lane (b, j) only has to supply output channel j's
+// weights as its A operand), so the lanes of one hardware group take the 16 columns of one row: conflict-free on the dense layout,
+// which keeps the patch at 46 KB (three workgroups per CU at CH = 16; padded rows would be 49 KB: two).  The filter operand has four
+// distinct addresses per group (output channel j = lane & 3), LDW floats apart so that they fall on different banks.
+constexpr int M4B_ROW = MS_PW * MS_CKP;
+__device__ __forceinline__ void m4b_lane_pixel(int lane, int& row, int& col) {  // row 0..3 of the 64-pixel set, column 0..15
+    const int l5 = lane & 31;
+    int grp, pos;
+    if (l5 < 4) { grp = 0; pos = l5; }
+    else if (l5 < 12) { grp = 1; pos = l5 - 4; }
+    else if (l5 < 16) { grp = 0; pos = l5 - 8; }
+    else if (l5 < 20) { grp = 1; pos = l5 - 8; }
+    else if (l5 < 28) { grp = 0; pos = l5 - 12; }
+    else { grp = 1; pos = l5 - 16; }
+    row = 2 * (lane >> 5) + grp;
+    col = pos;
+}
 
 template <int CH, int JB, int NS>
 struct Ms4bBranch {  // branch JB on NS consecutive 64-pixel sets (acc[0 .. NS-1]); pbase addresses the first set
-    static constexpr int C4 = CH / 4, RS = C4 / 4, ROW = M4B_ROW, SET = 4 * ROW, LDW = CH + 4;
+    static constexpr int C4 = CH / 4, RS = C4 / 4, ROW = M4B_ROW, SET = 4 * ROW, LDW = (CH == 16 ? CH : CH + 4);
     static constexpr int NSTEP = (JB == 0 ? 1 : 9) * 4;  // (tap, channel quad) steps of this branch per 16-channel chunk
     struct Ops {
         f32x4 a[RS], b[NS];
@@ -614,7 +627,7 @@ struct Ms4bBranch {  // branch JB on NS consecutive 64-pixel sets (acc[0 .. NS-1
 // 28 * C4 * CH scalars from the four PyTorch-layout tensors per tile
 template <int CH>
 __global__ void ms_pack_fwd4b_kernel(MsParamPtrs prm, float* __restrict__ wp) {
-    constexpr int C4 = CH / 4, LDW = CH + 4, TOTAL = 28 * C4 * LDW;
+    constexpr int C4 = CH / 4, LDW = (CH == 16 ? CH : CH + 4), TOTAL = 28 * C4 * LDW;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < TOTAL + CH; idx += gridDim.x * blockDim.x) {
         if (idx >= TOTAL) {
             const int co = idx - TOTAL;
@@ -632,12 +645,12 @@ __global__ void ms_pack_fwd4b_kernel(MsParamPtrs prm, float* __restrict__ wp) {
 // 16-byte loads per thread -- is in flight in registers while the current one is multiplied, so the only exposed memory latency is
 // the first patch's.
 template <int CH>
-__global__ __launch_bounds__(256, 2) void ms_fwd4b_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
+__global__ __launch_bounds__(256, CH == 16 ? 3 : 2) void ms_fwd4b_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y,
                                                           int N, int H, int W, int tiles_x, int tiles_y, int ntiles) {
-    constexpr int C4 = CH / 4, RS = C4 / 4, NCHK = CH / 16, NS = 4, LDW = CH + 4, NPF = M4_PH * MS_PW * 4 / 256;
+    constexpr int C4 = CH / 4, RS = C4 / 4, NCHK = CH / 16, NS = 4, LDW = (CH == 16 ? CH : CH + 4), NPF = M4_PH * MS_PW * 4 / 256;
     static_assert(M4_PH * MS_PW * 4 == NPF * 256, "patch quads divide evenly over the workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* patch = smem;                                  // [M4_PH][M4B_ROW]   one 16-channel chunk of x at a time, rows padded (above)
+    float* patch = smem;                                  // [M4_PH][PW][CKP]   one 16-channel chunk of x at a time
     float* wl = smem + M4_PH * M4B_ROW;                   // [28 taps][C4 co][LDW]   the whole filter, staged once
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t plane = (size_t)H * W;
@@ -668,10 +681,11 @@ __global__ __launch_bounds__(256, 2) void ms_fwd4b_kernel(const float* __restric
             pok |= (ok ? 1u : 0u) << k;
         }
     };
-    // lane (block b, j): pixel row 4*set + b/4, column 4*(b%4) + j ; supplies the weights of output channel 4*rs + j of its branch
-    const int b = lane >> 2, j = lane & 3;
-    const int pcol = 4 * (b & 3) + j;
-    const int pbase = ((b >> 2) + 4) * M4B_ROW + (pcol + 4) * MS_CKP;
+    // lane (block b, j = lane & 3) supplies the weights of output channel 4*rs + j of its branch; its pixel: m4b_lane_pixel
+    const int j = lane & 3;
+    int prow, pcol;
+    m4b_lane_pixel(lane, prow, pcol);
+    const int pbase = (prow + 4) * M4B_ROW + (pcol + 4) * MS_CKP;
     int tile = blockIdx.x;
     if (tile < ntiles) fetch(tile, 0);
     f32x4 acc[NS][RS];
@@ -722,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void ms_fwd4b_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int br = k == 3 ? 0 : (role == 3 ? k + 1 : role + 1), set = role == 3 ? 3 : (k == 3 ? role : k);
-            const int gy = ty0 * M4_TH + 4 * set + (b >> 2);
+            const int gy = ty0 * M4_TH + 4 * set + prow;
             if (gy < H && gx < W) {
                 float* p = y + (((size_t)n * H + gy) * W + gx) * CH + C4 * br;
 #pragma unroll
@@ -918,7 +932,8 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
         if ((use4 || use4b) && aligned && H >= 16) {
             constexpr int C4K = (CH <= 32 ? CH : 16);
             const int tiles_x = cdiv(W, 16), tiles_y = cdiv(H, M4_TH);
-            const size_t lds = use4b ? (size_t)(M4_PH * M4B_ROW + 28 * (C4K / 4) * (C4K + 4)) * sizeof(float)
+            constexpr int LDW4B = C4K == 16 ? C4K : C4K + 4;
+            const size_t lds = use4b ? (size_t)(M4_PH * M4B_ROW + 28 * (C4K / 4) * LDW4B) * sizeof(float)
                                      : (size_t)(M4_PH * MS_PW * MS_CKP + 28 * (C4K / 4) * C4K) * sizeof(float);
             static bool attr4 = false;
             if (!attr4) {
@@ -931,11 +946,11 @@ static int launch_ms_fwd(const float* x, const MsParamPtrs& prm, float* y, int N
                 attr4 = true;
             }
             if (use4b) {
-                constexpr int PACKED = 28 * (C4K / 4) * (C4K + 4) + C4K;
+                constexpr int PACKED = 28 * (C4K / 4) * LDW4B + C4K;
                 if (!ws || ws_bytes < (size_t)PACKED * sizeof(float)) return fail_arg(MSTG_E_WORKSPACE, "msblock_fwd: workspace too small");
                 MSTG_PACK_LAUNCH((ms_pack_fwd4b_kernel<C4K>), dim3(cdiv(PACKED, 256)), dim3(256), 0, st, prm, (float*)ws);
                 MSTG_CHECK_LAUNCH("ms_pack_fwd4b_kernel");
-                const int ntiles = N * tiles_x * tiles_y, slots = 2 * ms_cus();  // two workgroups fit a CU's LDS
+                const int ntiles = N * tiles_x * tiles_y, slots = (C4K == 16 ? 3 : 2) * ms_cus();  // workgroups a CU's LDS holds
                 MSTG_LAUNCH((ms_fwd4b_kernel<C4K>), dim3(ntiles < slots ? ntiles : slots), dim3(256), lds, st, x, (const float*)ws, y, N, H, W,
                             tiles_x, tiles_y, ntiles);
             } else MSTG_LAUNCH((ms_fwd4_kernel<C4K>), dim3(N * tiles_x * tiles_y), dim3(256), lds, st, x, prm, y, N, H, W, tiles_x, tiles_y);
