@@ -1004,6 +1004,10 @@ static int p32_plan(const IGemmArgs& a, P32Plan& p) {
             if (need <= 78 * 1024 && !(p.NF == 4 && cand[k] == 16)) { TH = cand[k]; wlds = pass == 0; }
         }
     if (!TH) { TH = 4; wlds = 0; }
+    // 1x1 convolutions on 32 channels are HBM-bound and carry the statistics / backward-sums epilogues of the folded norms: at four rows
+    // per wave those variants need 219-256 VGPRs (one or two workgroups per CU, 32-64 KB in flight per CU: 3.1-3.9 TB/s); at two rows
+    // per wave they reach 3.8-4.7 TB/s.  (The 16-channel ones are faster at four rows: measured both ways.)
+    if (a.KH == 1 && a.KW == 1 && p.NF == 2 && TH == 16) TH = 8;
     { const char* e = env_get(ENV_P32_TH); if (e && (atoi(e) == 4 || atoi(e) == 8 || atoi(e) == 16) && !(p.NF == 4 && atoi(e) == 16)) TH = atoi(e); }
     { const char* e = env_get(ENV_P32_WLDS); if (e) wlds = atoi(e) != 0; }
     if (patch_bytes_of(TH) >= ((size_t)1 << 30)) return fail_arg(MSTG_E_UNSUPPORTED, "conv_p32: patch needs more than 12 prefetch registers");
