@@ -97,14 +97,28 @@ class MultiScaleBlock(nn.Module):
 class _Stage(nn.Sequential):
     """conv(T) -> IN -> ReLU -> LocalAttention -> MultiScaleBlock with the reference's child indices 0..4."""
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, x_raw=False):
+        """x_raw: x is the RAW tensor in front of an InstanceNorm + ReLU still to be applied (the stem's, handed down by
+        EnhancedGenerator): folded into this stage's convolution where the kernels can normalise on load, applied here otherwise."""
         conv, att = self[0], self[3]
         transposed = isinstance(conv, nn.ConvTranspose2d)
         cout = conv.out_channels
+        pre = None
+        if x_raw:
+            if (not transposed and conv.kernel_size == (4, 4) and conv.stride == (2, 2) and conv.padding == (1, 1)
+                    and os.environ.get("MSTG_NORM_STEM", "1") != "0"
+                    and ops.norm_conv_supported(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, 4, 2, 1, 1)):
+                pre = ops.MSFusionFn.apply(x, conv.weight, conv.bias, (4, 2, 1, 1))  # (conv output, its statistics)
+            else:
+                x = ops.instnorm_act(x, ACT_RELU)
         fold = (att.window_size == 4 and ops.fused_attention_supported(cout) and os.environ.get("MSTG_ATTN_UNFUSED") != "1"
                 and os.environ.get("MSTG_NORM_ATTN", "1") != "0")
         stats = None
-        if (fold and os.environ.get("MSTG_NORM_EPILOGUE", "1") != "0" and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
+        if pre is not None:
+            x, stats = pre
+            if not (fold and x.shape[1] % 4 == 0 and x.shape[2] % 4 == 0) or os.environ.get("MSTG_NORM_EPILOGUE", "1") == "0":
+                stats = None
+        elif (fold and os.environ.get("MSTG_NORM_EPILOGUE", "1") != "0" and conv.kernel_size == (4, 4) and conv.stride == (2, 2)
                 and conv.padding == (1, 1) and ops.conv_stats_pays(x.shape[0], x.shape[1], x.shape[2], x.shape[3], cout, 4, 2, 1, 1,
                                                                    transposed)):
             # the norm's statistics come out of the convolution's epilogue: no pass over the tensor for them
@@ -237,9 +251,13 @@ class EnhancedGenerator(nn.Module):
             return self._half().forward(x, taps)
         orig_input = x
         h = self.initial[0](x, nhwc=True, x_nchw=True)          # NCHW image -> NHWC features inside the stem conv
-        h = ops.instnorm_act(h, ACT_RELU)
-        if taps is not None: taps["initial"] = h
-        h = self._run(self.down1.forward_nhwc, h)
+        if taps is None:
+            # the stem's IN + ReLU has one consumer, down1's convolution: handed down raw, the normalised tensor is never written
+            h = self._run(self.down1.forward_nhwc, h, True)
+        else:
+            h = ops.instnorm_act(h, ACT_RELU)
+            taps["initial"] = h
+            h = self._run(self.down1.forward_nhwc, h)
         if taps is not None: taps["down1"] = h
         h = self._run(self.down2.forward_nhwc, h)
         if taps is not None: taps["down2"] = h

@@ -49,6 +49,7 @@ struct WGradArgs {
     int htw;        // LDS grid-tile row length in pixels (16, or 20 for dpack)
     int xshift;     // walked-grid column offset (3 for dpack, else 0)
     int with_bias;  // also emit per-split column sums of the grid tensor (Conv2d bias gradient) after the T*Cg*Ch block
+    const float* g_stats;  // wgrad_p32_kernel: the gathered tensor is RAW, in front of InstanceNorm + ReLU; (mean, rstd) [N][Cg][2]
 };
 
 constexpr int WT_H = 8, WT_W = 16;
@@ -440,6 +441,7 @@ constexpr int WP_TH = 4, WP_NFHT = 2, WP_UW = 8, WP_NG = 6, WP_NH = 2;  // 10 x 
 
 struct WpRegs {
     f32x4 gv[WP_NG], hv[WP_NH];
+    f32x4 st_lo, st_hi;  // g_stats: (mean, rstd) x 4 channels of this thread's patch quad (the same quad for all its elements), image of the tile
     unsigned gok, hok;
 };
 
@@ -461,6 +463,11 @@ __device__ __forceinline__ void wp_fetch(const WGradArgs& a, int tile, int tid, 
         R.gok |= (unsigned)ok << k;
         const unsigned off = ok ? (unsigned)((((y0 + pr) * a.gW + x0 + pc) * a.Cg + 4 * (e & 3)) * 4) : 0u;
         R.gv[k] = *reinterpret_cast<const f32x4*>(gimg + off);
+    }
+    if (a.g_stats) {
+        const float* st = a.g_stats + ((size_t)n * a.Cg + g0 + 4 * (tid & 3)) * 2;
+        R.st_lo = *reinterpret_cast<const f32x4*>(st);
+        R.st_hi = *reinterpret_cast<const f32x4*>(st + 4);
     }
     const int gy0 = ty0 * WP_TH, gx0 = tx0 * WT_W;
     R.hok = 0;
@@ -501,7 +508,16 @@ __global__ __launch_bounds__(256, 3) void wgrad_p32_kernel(const WGradArgs a) {
 #pragma unroll
         for (int k = 0; k < WP_NG; ++k) {
             const int e = 256 * k + tid;
-            if (e < total) *reinterpret_cast<f32x4*>(&patch[(e >> 2) * ckp + 4 * (e & 3)]) = ((R.gok >> k) & 1) ? R.gv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e < total) {
+                f32x4 w = ((R.gok >> k) & 1) ? R.gv[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.g_stats && ((R.gok >> k) & 1)) {  // norm_apply_kernel's arithmetic; the zero padding is of the NORMALISED tensor
+                    w[0] = fmaxf((w[0] - R.st_lo[0]) * R.st_lo[1], 0.f);
+                    w[1] = fmaxf((w[1] - R.st_lo[2]) * R.st_lo[3], 0.f);
+                    w[2] = fmaxf((w[2] - R.st_hi[0]) * R.st_hi[1], 0.f);
+                    w[3] = fmaxf((w[3] - R.st_hi[2]) * R.st_hi[3], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(&patch[(e >> 2) * ckp + 4 * (e & 3)]) = w;
+            }
         }
 #pragma unroll
         for (int k = 0; k < WP_NH; ++k) {
@@ -1311,8 +1327,13 @@ extern "C" size_t mstg_conv2d_wgrad_workspace_bytes(const mstg_conv_desc* d) {
     return w > w_11 ? w : w_11;
 }
 
-static bool wgrad_norm_ok(const WGradArgs& a) {  // normalise-on-load exists in the 1x1 kernel, for pixel runs that stay inside one image
-    if (!wgrad_1x1_ok(a) || a.g_coff != 0) return false;
+static bool wgrad_ts_path(const WGradArgs& a) {
+    return a.Teff == 16 && a.mode == MODE_PLAIN && a.Ch > 16 && a.Ch <= wgrad_ts_max_ch() &&
+           !(env_get(ENV_WGRAD_OLD) && env_get(ENV_WGRAD_OLD)[0] == '1');
+}
+static bool wgrad_norm_ok(const WGradArgs& a) {  // normalise-on-load exists in the persistent 4x4 stride-2 kernel and in the 1x1 kernel
+    if (!wgrad_1x1_ok(a)) return wgrad_ts_path(a) && wp_ok(a);
+    if (a.g_coff != 0) return false;  // 1x1: for pixel runs that stay inside one image
     const W11Chunks c = wgrad_1x1_chunks(a);
     for (int ig = 0; ig < c.ng; ++ig)
         for (int ih = 0; ih < c.nh; ++ih) {
@@ -1387,6 +1408,7 @@ static int conv2d_wgrad_impl(const mstg_conv_desc* d, const float* x, const floa
     } else if (use_ts && !(env_get(ENV_WGRAD_OLD) && env_get(ENV_WGRAD_OLD)[0] == '1')) {
         const TsPlan p = plan_ts(a);
         if (wp_ok(a)) {  // persistent, prefetching form of the same kernel
+            a.g_stats = in_stats;
             WpPlan q = wp_plan(a);
             if (workspace_bytes < q.ws_bytes) return fail_arg(MSTG_E_WORKSPACE, "conv_wgrad: workspace too small");
             if (int rc = launch_wp(a, q, st)) return rc;

@@ -483,28 +483,32 @@ class MSFusionFn(torch.autograd.Function):
     """f = Conv1x1(ReLU(InstanceNorm2d(cat))) of the MultiScaleBlock (enhanced_generator.py:72-75, 83) without the normalised concat
     ever being written: one statistics pass over the raw concat, then the fusion convolution normalises while it stages its tiles;
     in the backward the 1x1 weight-gradient kernel does the same, and the norm's own backward works from the raw tensor as always.
-    Two tensor passes fewer per block than norm kernel + convolution, with the same arithmetic on every element."""
+    Two tensor passes fewer per block than norm kernel + convolution, with the same arithmetic on every element.
+    cfg = (k, stride, pad, dil) (default 1x1): the same fold for the stem's InstanceNorm + ReLU in front of down1's 4x4 stride-2
+    convolution (enhanced_generator.py:93-95 -> :97), where the persistent convolution / weight-gradient kernels normalise on load."""
 
     @staticmethod
-    def forward(ctx, cat, w, b):
+    def forward(ctx, cat, w, b, cfg=(1, 1, 0, 1)):
         lib = _lib.load()
         cat, w = _req(cat, "fusion input"), _req(w, "fusion weight")
         b = None if b is None else _req(b, "fusion bias")
         N, H, W, Cn = cat.shape
         Cout = w.shape[0]
+        k, stride, pad, dil = cfg
+        Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, False)
         stats = torch.empty((N, Cn, 2), dtype=torch.float32, device=cat.device)
         ws = _ws(lib.mstg_norm_workspace_bytes(N, H * W, Cn), cat.device)
         _timed("norm_partial_kernel<false>", 0, 4 * cat.numel(), lambda: _lib.check(
             lib.mstg_norm_stats(_p(cat), _p(stats), N, H * W, Cn, _p(ws), ws.numel() * 4, _stream()), "mstg_norm_stats"))
-        y = torch.empty((N, H, W, Cout), dtype=torch.float32, device=cat.device)
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=cat.device)
         ystats = torch.empty((N, Cout, 2), dtype=torch.float32, device=cat.device)  # (mean, rstd) of y from the epilogue
-        d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
+        d = make_desc(N, H, W, Cn, Ho, Wo, Cout, k, stride, pad, dil)
         ws2, packed = _cached_ws((w, b), "fwd_norm", _dkey(d, 0), lib.mstg_conv2d_fwd_norm_workspace_bytes(C.byref(d)), cat.device)
         fl, by = _conv_cost(d)
         _timed(_kernel_name(d, 0).replace(", false>", ", true>"), fl, by, lambda: _lib.check(
             lib.mstg_conv2d_fwd_norm_cached(C.byref(d), _p(cat), _p(stats), _p(w), _p(b), _p(y), _p(ystats), _p(ws2), ws2.numel() * 4,
                                             packed, _stream()), "mstg_conv2d_fwd_norm"), _conv_detail("fwd", d))
-        ctx.dims, ctx.has_bias, ctx.prefs = (N, H, W, Cn, Cout), b is not None, (w, b)
+        ctx.dims, ctx.has_bias, ctx.prefs, ctx.cfg = (N, H, W, Cn, Cout), b is not None, (w, b), tuple(cfg)
         ctx.save_for_backward(cat, stats, w)
         ctx.mark_non_differentiable(ystats)
         return y, ystats
@@ -515,7 +519,9 @@ class MSFusionFn(torch.autograd.Function):
         N, H, W, Cn, Cout = ctx.dims
         cat, stats, w = ctx.saved_tensors
         dy = _req(dy, "fusion grad_output")
-        d = make_desc(N, H, W, Cn, H, W, Cout, 1, 1, 0, 1)
+        k, stride, pad, dil = ctx.cfg
+        Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, False)
+        d = make_desc(N, H, W, Cn, Ho, Wo, Cout, k, stride, pad, dil)
         dcat = dw = db = None
         if ctx.needs_input_grad[0]:
             dz = torch.empty_like(cat)
@@ -547,8 +553,17 @@ class MSFusionFn(torch.autograd.Function):
                 lib.mstg_conv2d_wgrad_norm(C.byref(d), _p(cat), _p(stats), _p(dy), _p(out_w), _p(out_b), _p(wsw), wsw.numel() * 4, _stream()),
                 "mstg_conv2d_wgrad_norm"), _conv_detail("wgrad", d))
         elif ctx.has_bias and ctx.needs_input_grad[2]:
-            db = channel_sum(dy, N * H * W, Cout, 0, Cout)
-        return dcat, dw, db
+            db = channel_sum(dy, N * Ho * Wo, Cout, 0, Cout)
+        return dcat, dw, db, None
+
+
+def norm_conv_supported(N, H, W, Cin, Cout, k, stride, pad, dil) -> bool:
+    """MSFusionFn's fold for a k x k convolution: forward with in- and out-statistics and the weight gradient with in-statistics."""
+    if not conv_stats_pays(N, H, W, Cin, Cout, k, stride, pad, dil, False):
+        return False
+    Ho, Wo = conv_out_hw(H, W, k, stride, pad, dil, False)
+    d = make_desc(N, H, W, Cin, Ho, Wo, Cout, k, stride, pad, dil)
+    return bool(_lib.load().mstg_conv2d_wgrad_norm_supported(C.byref(d)))
 
 
 def conv2d_stats(x, w, b, k, stride=1, pad=0, dil=1, transposed=False):

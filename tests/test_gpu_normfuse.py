@@ -216,6 +216,34 @@ def test_ms_fusion_folded_norm_vs_chain(N, H, W, Cn):
         report(f"ms fusion N{N} {H}x{W} C{Cn} {name} vs torch", rel_l2(a_, b_), 1e-4)
 
 
+@pytest.mark.parametrize("N,H,W,Ci,Co", [(2, 64, 64, 16, 32), (3, 32, 48, 16, 32), (1, 256, 256, 16, 32)])
+def test_stem_norm_folded_into_stride2_conv_vs_chain(N, H, W, Ci, Co):
+    """The stem's IN + ReLU folded into down1's 4x4 stride-2 convolution (MSFusionFn with cfg (4, 2, 1, 1): normalise-on-load in
+    conv_p32_kernel and, for the weight gradient, in wgrad_p32_kernel) against norm kernels + convolution: the forward is the same
+    arithmetic on every element (bit-identical), gradients within summation-order noise; and against torch fp32 on the CPU."""
+    from mstg_hip import ops
+    assert ops.norm_conv_supported(N, H, W, Ci, Co, 4, 2, 1, 1)
+    x = rnd((N, H, W, Ci), 51, 1.4) + 0.3
+    w, b = rnd((Co, Ci, 4, 4), 52, (Ci * 16) ** -0.5), rnd((Co,), 53, 0.3)
+    dy = rnd((N, H // 2, W // 2, Co), 54)
+    outs = []
+    for fused in (True, False):
+        t = [v.to(DEV).requires_grad_(True) for v in (x, w, b)]
+        f = ops.MSFusionFn.apply(t[0], t[1], t[2], (4, 2, 1, 1))[0] if fused else ops.conv2d(ops.instnorm_act(t[0], ops.ACT_RELU), t[1], t[2], 4, 2, 1)
+        g = torch.autograd.grad((f * dy.to(DEV)).sum(), t)
+        outs.append((f.detach().cpu(), [v.cpu() for v in g]))
+    assert torch.equal(outs[0][0], outs[1][0]), rel_l2(outs[0][0], outs[1][0])
+    for name, a_, b_ in zip(("dx", "dw", "db"), outs[0][1], outs[1][1]):
+        report(f"stem fold N{N} {H}x{W} {Ci}->{Co} {name} vs chain", rel_l2(a_, b_), 2e-6)
+    t = [v.clone().requires_grad_(True) for v in (x, w, b)]
+    z = F.relu(F.instance_norm(t[0].permute(0, 3, 1, 2), eps=1e-5))
+    fr = F.conv2d(z, t[1], t[2], stride=2, padding=1).permute(0, 2, 3, 1)
+    gr = torch.autograd.grad((fr * dy).sum(), t)
+    report(f"stem fold N{N} {H}x{W} {Ci}->{Co} f vs torch", rel_l2(outs[0][0], fr.detach()), 2e-5)
+    for name, a_, b_ in zip(("dx", "dw", "db"), outs[0][1], gr):
+        report(f"stem fold N{N} {H}x{W} {Ci}->{Co} {name} vs torch", rel_l2(a_, b_), 1e-4)
+
+
 def test_ms_fusion_not_offered_when_a_pixel_run_would_cross_images():
     from mstg_hip import ops
     assert not ops.ms_fusion_supported(2, 6, 6, 16)  # 36 pixels per image, 256-pixel runs
@@ -248,7 +276,8 @@ def test_ms_fusion_output_statistics_and_apply(N, H, W, Cn):
         report(f"fusion+stats N{N} {H}x{W} C{Cn} {name} vs chain", rel_l2(a_, b_), 2e-5)
 
 
-@pytest.mark.parametrize("env", ["MSTG_NORM_ATTN=0", "MSTG_NORM_EPILOGUE=0", "MSTG_NORM_FUSION=0", "MSTG_P32=0", "MSTG_NORM_BSUMS=0", "MSTG_NO_PACK_CACHE=1"])
+@pytest.mark.parametrize("env", ["MSTG_NORM_ATTN=0", "MSTG_NORM_EPILOGUE=0", "MSTG_NORM_FUSION=0", "MSTG_NORM_STEM=0", "MSTG_P32=0", "MSTG_NORM_BSUMS=0",
+                                 "MSTG_NO_PACK_CACHE=1"])
 def test_generator_same_with_every_norm_folding_switched_off(env, monkeypatch):
     """The folded InstanceNorms and the persistent kernels are optimisations of the same arithmetic: the generator's output and all
     parameter gradients with each of them switched off agree with the default path.  Forward: <= 5e-5 on every draw.  Gradients:
