@@ -307,17 +307,35 @@ class EnhancedDiscriminator(nn.Module):
     def _sn_convs(self):
         return [self.main[0], self.main[2], self.main[5], self.main[8], self.batch_head[0], self.structure_head[0], self.structure_head[3]]
 
-    def forward(self, x):
+    def forward(self, x, outputs="both"):
+        """(score, structure) like the reference (:256-274).  ``outputs`` = "score" / "struct" is a hint from the train step about the
+        head whose result it discards; it is honoured only with MSTG_D_SKIP_DEAD_HEADS=1 (that head then comes back as None; every
+        weight still takes its power iteration for this forward -- the grouped spectral norm normalises all seven -- so the other head
+        and the state are exactly what a full forward gives)."""
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"EnhancedDiscriminator expects (N,3,H,W), got {tuple(x.shape)}")
-        if self._sn_grouped and os.environ.get("MSTG_SN_GROUP", "1") != "0":
+        grouped = self._sn_grouped and os.environ.get("MSTG_SN_GROUP", "1") != "0"
+        if grouped:
             ops.spectral_norm_group(self._sn_convs())
+        if not grouped or outputs not in ("score", "struct") or os.environ.get("MSTG_D_SKIP_DEAD_HEADS", "0") != "1":
+            # default: both heads run, as in the reference, even where the train step discards one (the bench times the reference's
+            # work); opt-in MSTG_D_SKIP_DEAD_HEADS=1 drops the discarded head (-38 launches, -0.4 ms per step, same losses / gradients /
+            # state).  With per-module hooks a skipped convolution would also skip its power iteration: never skipped then.
+            outputs = "both"
         m = self.main
         h = ops.activation(m[0](x, nhwc=True, x_nchw=True), ACT_LEAKY02)
         for ci in (2, 5, 8):
             h = ops.instnorm_act(m[ci](h, nhwc=True), ACT_LEAKY02)
         N = h.shape[0]
-        score = ops.spatial_mean(self.batch_head[0](h, nhwc=True))             # (N, 1)
-        s = ops.instnorm_act(self.structure_head[0](h, nhwc=True), ACT_LEAKY02)
-        st = self.structure_head[3](s, nhwc=True)                               # (N, h, w, 1) == NCHW (N, 1, h, w)
-        return score.view(N, 1, 1, 1).squeeze(), st.permute(0, 3, 1, 2)
+        score = st = None
+        if outputs != "struct":
+            score = ops.spatial_mean(self.batch_head[0](h, nhwc=True)).view(N, 1, 1, 1).squeeze()   # (N, 1)
+        else:
+            self.batch_head[0].__dict__.pop("_mstg_sn_fresh", None)  # its hook does not run: drop the marker the group call left
+        if outputs != "score":
+            s = ops.instnorm_act(self.structure_head[0](h, nhwc=True), ACT_LEAKY02)
+            st = self.structure_head[3](s, nhwc=True).permute(0, 3, 1, 2)       # (N, h, w, 1) == NCHW (N, 1, h, w)
+        else:
+            for mod in (self.structure_head[0], self.structure_head[3]):
+                mod.__dict__.pop("_mstg_sn_fresh", None)
+        return score, st

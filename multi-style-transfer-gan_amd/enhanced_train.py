@@ -199,12 +199,12 @@ class EnhancedCycleGAN:
         self.d_optimizer.zero_grad(set_to_none=True)
         fork()
         with on(sC):
-            real_A_score, _ = D_A(real_A)
-            fake_A_score, _ = D_A(fake_A.detach())
+            real_A_score, _ = D_A(real_A, outputs="score")  # the structure head's output is discarded here (:67-85)
+            fake_A_score, _ = D_A(fake_A.detach(), outputs="score")
             dA_real, dA_fake = ops.mse_to_const(real_A_score, 1.0), ops.mse_to_const(fake_A_score, 0.0)
         with on(sD):
-            real_B_score, _ = D_B(real_B)
-            fake_B_score, _ = D_B(fake_B.detach())
+            real_B_score, _ = D_B(real_B, outputs="score")
+            fake_B_score, _ = D_B(fake_B.detach(), outputs="score")
             dB_real, dB_fake = ops.mse_to_const(real_B_score, 1.0), ops.mse_to_const(fake_B_score, 0.0)
         join(dA_real, dA_fake, dB_real, dB_fake)
         # (dA_real + dB_real) * 0.5 + (dA_fake + dB_fake) * 0.5 (:72-81) as one weighted sum (one launch each way)
@@ -254,22 +254,22 @@ class EnhancedCycleGAN:
                 sC.wait_stream(upd)
                 sD.wait_stream(upd)
             with on(sD):
-                fake_B_score, fake_B_struct = D_B(fake_B)
+                fake_B_score, _ = D_B(fake_B, outputs="score")  # its structure output is overwritten two lines down (:110-113)
                 gB = ops.mse_to_const(fake_B_score, 1.0)
                 with torch.no_grad():
-                    _, real_B_struct = D_B(real_B)
-                _, fake_B_struct = D_B(fake_B)
+                    _, real_B_struct = D_B(real_B, outputs="struct")
+                _, fake_B_struct = D_B(fake_B, outputs="struct")
                 sB_l = ops.l1_loss(real_B_struct, fake_B_struct)
             if not recon_first:
                 with on(sB):
                     recon_A = G_BA(fake_B)
                     cA = ops.l1_loss(recon_A, real_A)
             with on(sC):
-                fake_A_score, fake_A_struct = D_A(fake_A)
+                fake_A_score, _ = D_A(fake_A, outputs="score")
                 gA = ops.mse_to_const(fake_A_score, 1.0)
                 with torch.no_grad():
-                    _, real_A_struct = D_A(real_A)
-                _, fake_A_struct = D_A(fake_A)
+                    _, real_A_struct = D_A(real_A, outputs="struct")
+                _, fake_A_struct = D_A(fake_A, outputs="struct")
                 sA_l = ops.l1_loss(real_A_struct, fake_A_struct)
             join(gA, gB, cA, cB, sA_l, sB_l)
             # g + cycle * lambda + identity * lambda + structure * lambda (:95-118): the total as ONE weighted sum over the eight terms

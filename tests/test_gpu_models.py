@@ -738,7 +738,8 @@ def test_train_step_schedules_are_bit_identical():
         assert torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2]), (ckpt, streams)
 
 
-@pytest.mark.parametrize("env", ["MSTG_ATTN_UNFUSED=1", "MSTG_TORCH_SPECTRAL_NORM=1", "MSTG_SN_GROUP=0", "MSTG_STREAMS=4", "MSTG_STREAMS=0",
+@pytest.mark.parametrize("env", ["MSTG_ATTN_UNFUSED=1", "MSTG_TORCH_SPECTRAL_NORM=1", "MSTG_SN_GROUP=0", "MSTG_D_SKIP_DEAD_HEADS=1", "MSTG_STREAMS=4",
+                                 "MSTG_STREAMS=0",
                                  "MSTG_IGEMM=l", "MSTG_IGEMM=h", "MSTG_STREAM=1"])
 def test_module_level_switches_keep_parity(env, gold_dir, monkeypatch):
     """The module-level switches of INTEGRATION.md section 3 (unfused attention, torch's spectral-norm hook, stream counts, conv
