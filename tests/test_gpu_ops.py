@@ -303,7 +303,9 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
 
 
 NORM_CASES = [(2, 16, 24, 8, 1), (1, 64, 64, 16, 1), (3, 7, 9, 32, 2), (2, 4, 4, 64, 2), (1, 128, 128, 16, 1), (2, 2, 2, 64, 2),
-              (2, 16, 16, 4, 0), (1, 32, 32, 128, 1)]
+              (2, 16, 16, 4, 0), (1, 32, 32, 128, 1),
+              # small batches of large maps: more than 32 partial rows per image, added once by the grouped statistics / sums kernels
+              (1, 96, 96, 24, 1), (2, 128, 96, 64, 2), (1, 160, 128, 256, 1)]
 
 
 @pytest.mark.parametrize("N,H,W,C,act", NORM_CASES)
