@@ -1390,6 +1390,183 @@ __global__ __launch_bounds__(256) void attn_f16_kernel(const h16* __restrict__ x
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------------
+// The same module as register-resident MFMA chains (round 3; the fp32 training kernels' design, csrc/attention_reg.hip): the
+// accumulator layout of v_mfma_f32_16x16x16_f16 -- register r of lane (i, g) is D[4g + r][i] -- is, after rounding the four values to
+// fp16, exactly the 4-element operand of a following MFMA that contracts over D's ROW index.  A window fetched with one 8-byte load
+// per lane and 16-channel fragment (lane i = pixel, channels 16h + 4g ..) serves as the A operand (rows = pixels) and as the B
+// operand (columns = pixels), so q | k -> S^T -> softmax -> O^T -> Y^T run without a single LDS tile: attn_f16_kernel moved seven
+// tiles per window through LDS (41 % of its LDS cycles, 44 % of them bank conflicts) and ran at 0.8-3.1 TB/s.  Filters in registers
+// at C <= 32 (the packed fragments are already in operand layout), in LDS at C = 64.  Persistent waves over contiguous window
+// ranges, the next window's pixels in flight behind the current chain.  Rounding points are attn_f16_kernel's (q^, k^, v, P, O in fp16;
+// accumulation, norms and softmax in fp32).
+// -------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ h16x4v cvt4(f32x4 v) { return h16x4v{(h16)v[0], (h16)v[1], (h16)v[2], (h16)v[3]}; }
+__device__ __forceinline__ float xg_sum_f(float v) {  // sum over the four lanes sharing i = lane & 15
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256, C == 64 ? 2 : 3) void attn_f16r_kernel(const h16* __restrict__ x, const float* __restrict__ in_stats,
+                                                                          const h16* __restrict__ wfrag, const float* __restrict__ bias,
+                                                                          h16* __restrict__ y, int N, int H, int W) {
+    constexpr int NB = C / 16, NFRAG = 4 * NB * NB;
+    constexpr bool WLDS = C > 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, l = tid & 63, i = l & 15, g = l >> 4;
+    h16x4v wr[WLDS ? 1 : NFRAG];
+    if (WLDS) {
+        for (int e = tid; e < NFRAG * 64; e += 256) reinterpret_cast<h16x4v*>(smem)[e] = reinterpret_cast<const h16x4v*>(wfrag)[e];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) wr[f] = reinterpret_cast<const h16x4v*>(wfrag)[f * 64 + l];
+    }
+    auto wget = [&](int part, int f, int ks) -> h16x4v {  // lane (i, g): W[part * C + 16 f + i][16 ks + 4 g + j]
+        const int idx = (part * NB + f) * NB + ks;
+        if (WLDS) return reinterpret_cast<const h16x4v*>(smem)[idx * 64 + l];
+        return wr[WLDS ? 0 : idx];
+    };
+    const int nwx = W / 4, nwy = H / 4, nwin = N * nwx * nwy;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6)), nwv = gridDim.x * 4;
+    const int per = (nwin + nwv - 1) / nwv, w0 = wv * per, w1 = w0 + per < nwin ? w0 + per : nwin;
+    if (w0 >= nwin) return;
+    float bq[NB], bk[NB];
+    f32x4 bv[NB], bp[NB];
+#pragma unroll
+    for (int f = 0; f < NB; ++f) {
+        bq[f] = bias[16 * f + i];
+        bk[f] = bias[C + 16 * f + i];
+        bv[f] = *reinterpret_cast<const f32x4*>(bias + 2 * C + 16 * f + 4 * g);
+        bp[f] = *reinterpret_cast<const f32x4*>(bias + 3 * C + 16 * f + 4 * g);
+    }
+    // window coordinates: wave-uniform walkers advanced by carries -- one for the window being fetched, one for the window being computed
+    struct Walk {
+        int n, wy, wx;
+        __device__ __forceinline__ void next(int nwx_, int nwy_) {
+            if (++wx == nwx_) {
+                wx = 0;
+                if (++wy == nwy_) { wy = 0; ++n; }
+            }
+        }
+    };
+    Walk fw{w0 / (nwx * nwy), (w0 / nwx) % nwy, w0 % nwx}, pw = fw;
+    auto fetch = [&](h16x4v (&t)[NB], const Walk& c) {
+        const h16* p = x + (((size_t)c.n * H + 4 * c.wy + (i >> 2)) * W + 4 * c.wx + (i & 3)) * C + 4 * g;
+#pragma unroll
+        for (int h = 0; h < NB; ++h) t[h] = *reinterpret_cast<const h16x4v*>(p + 16 * h);
+    };
+    // DEPTH windows are fetched as a group while the previous group is computed.  Measured: 4 instead of 1 changes nothing at C = 16 and
+    // costs 12 % at C = 32 (a wave per SIMD less) -- at 155 / 240 VALU instructions per window against 6 / 24 MFMAs the kernel is bound
+    // by the vector pipe (row sums of the two F.normalize, conversions, softmax), not by loads in flight.
+    constexpr int DEPTH = 1;
+    h16x4v nxt[DEPTH][NB];
+    int fwin = w0;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (fwin < w1) { fetch(nxt[d], fw); fw.next(nwx, nwy); ++fwin; }
+    for (int win = w0; win < w1; win += DEPTH) {
+        h16x4v cur[DEPTH][NB];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int h = 0; h < NB; ++h) cur[d][h] = nxt[d][h];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (fwin < w1) { fetch(nxt[d], fw); fw.next(nwx, nwy); ++fwin; }
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        if (win + d >= w1) break;
+        const int cn = pw.n, cwy = pw.wy, cwx = pw.wx;
+        pw.next(nwx, nwy);
+        h16x4v xa[NB];
+        if (in_stats) {  // (x - mean) * rstd, ReLU, as attn_f16_kernel applies it while staging: fp32 arithmetic, one rounding to fp16
+#pragma unroll
+            for (int h = 0; h < NB; ++h) {
+                const float* st = in_stats + ((size_t)cn * C + 16 * h + 4 * g) * 2;
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1 = *reinterpret_cast<const f32x4*>(st + 4);
+                xa[h][0] = (h16)fmaxf(fmaf((float)cur[d][h][0], s0[1], -s0[0] * s0[1]), 0.f);
+                xa[h][1] = (h16)fmaxf(fmaf((float)cur[d][h][1], s0[3], -s0[2] * s0[3]), 0.f);
+                xa[h][2] = (h16)fmaxf(fmaf((float)cur[d][h][2], s1[1], -s1[0] * s1[1]), 0.f);
+                xa[h][3] = (h16)fmaxf(fmaf((float)cur[d][h][3], s1[3], -s1[2] * s1[3]), 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NB; ++h) xa[h] = cur[d][h];
+        }
+        // q | k = X W^T: L(p|j); v^T = Wv X^T: L(c|p)
+        f32x4 q[NB], k[NB], vt[NB];
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            q[f] = f32x4{bq[f], bq[f], bq[f], bq[f]};
+            k[f] = f32x4{bk[f], bk[f], bk[f], bk[f]};
+            vt[f] = bv[f];
+#pragma unroll
+            for (int h = 0; h < NB; ++h) {
+                q[f] = mfma16h(xa[h], wget(0, f, h), q[f]);
+                k[f] = mfma16h(xa[h], wget(1, f, h), k[f]);
+                vt[f] = mfma16h(wget(2, f, h), xa[h], vt[f]);
+            }
+        }
+        // F.normalize over channels: a row (g, r) is a pixel, its channels lie across the 16 lanes and NB fragments
+        f32x4 sq = {0.f, 0.f, 0.f, 0.f}, sk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            sq += q[f] * q[f];
+            sk += k[f] * k[f];
+        }
+        f32x4 iq, ik;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            iq[r] = fminf(__builtin_amdgcn_rsqf(row16_sum_f(sq[r])), 1e12f);
+            ik[r] = fminf(__builtin_amdgcn_rsqf(row16_sum_f(sk[r])), 1e12f);
+        }
+        h16x4v qh[NB], kh[NB], vh[NB];
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            qh[f] = cvt4(q[f] * iq);
+            kh[f] = cvt4(k[f] * ik);
+            vh[f] = cvt4(vt[f]);
+        }
+        // S^T[c2][c1] = sum_p k^[p][c2] q^[p][c1]; softmax over c2 (rows: registers + the four lane groups); |S| <= 1
+        h16x4v pt[NB][NB];
+#pragma unroll
+        for (int nn = 0; nn < NB; ++nn) {
+            f32x4 st[NB];
+            float z = 0.f;
+#pragma unroll
+            for (int m = 0; m < NB; ++m) {
+                st[m] = mfma16h(kh[m], qh[nn], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { st[m][r] = __expf(st[m][r]); z += st[m][r]; }
+            }
+            const float inv = __builtin_amdgcn_rcpf(xg_sum_f(z));
+#pragma unroll
+            for (int m = 0; m < NB; ++m) pt[m][nn] = cvt4(st[m] * f32x4{inv, inv, inv, inv});
+        }
+        // O^T[c1][p] = sum_c2 P^T[c2][c1] v^T[c2][p];  Y^T[co][p] = bp[co] + sum_c1 Wp[co][c1] O^T[c1][p]
+        h16x4v oh[NB];
+#pragma unroll
+        for (int n1 = 0; n1 < NB; ++n1) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < NB; ++m) o = mfma16h(pt[m][n1], vh[m], o);
+            oh[n1] = cvt4(o);
+        }
+        h16* yp = y + (((size_t)cn * H + 4 * cwy + (i >> 2)) * W + 4 * cwx + (i & 3)) * C + 4 * g;
+#pragma unroll
+        for (int cf = 0; cf < NB; ++cf) {
+            f32x4 acc = bp[cf];
+#pragma unroll
+            for (int n1 = 0; n1 < NB; ++n1) acc = mfma16h(wget(3, cf, n1), oh[n1], acc);
+            *reinterpret_cast<h16x4v*>(yp + 16 * cf) = cvt4(acc);
+        }
+      }
+    }
+}
+
 // wqkv (3C, C), wproj (C, C) fp32 -> fragments [part][f][ks][lane][4]: lane (i, g) holds W[part*C + 16f + i][16ks + 4g + j]
 __global__ void f16_attn_pack_kernel(const float* __restrict__ wqkv, const float* __restrict__ bqkv, const float* __restrict__ wproj,
                                      const float* __restrict__ bproj, int C, h16* __restrict__ wfrag, float* __restrict__ bias) {
@@ -1431,6 +1608,23 @@ static int launch_attn_f16(const void* x, const float* in_stats, const void* blo
     if (lds > 64 * 1024 && !attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
+    }
+    const char* e_reg = getenv("MSTG_F16_ATTN_REG");
+    if (!(e_reg && e_reg[0] == '0')) {  // register-resident chains (default); MSTG_F16_ATTN_REG=0: the LDS-tile kernel of round 2
+        const size_t lds_r = T::WLDS ? (size_t)T::NFRAG * 64 * 8 : 0;
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+            if (cus <= 0) cus = 256;
+        }
+        const int nwin = N * (H / 4) * (W / 4);
+        int nb = cus * (C == 64 ? 2 : (C == 32 ? 4 : 8));  // persistent workgroups: what the kernel's registers allow per SIMD
+        if (nb * 4 > nwin) nb = cdiv(nwin, 4);
+        MSTG_LAUNCH((attn_f16r_kernel<C>), dim3(nb), dim3(256), lds_r, st, (const h16*)x, in_stats, wfrag, bias, (h16*)y, N, H, W);
+        MSTG_CHECK_LAUNCH("attn_f16r_kernel");
+        return MSTG_OK;
     }
     dim3 grid(cdiv(W / 4, 4 * ATT_WPW), H / 4, N);
     MSTG_LAUNCH((attn_f16_kernel<C>), grid, dim3(256), lds, st, (const h16*)x, in_stats, wfrag, bias, (h16*)y, N, H, W);

@@ -119,8 +119,13 @@ def test_f16_head_tanh_nchw():
     report("head 7x7 16->3 tanh NCHW", rel_l2(y.float(), ref), 2e-3)
 
 
-@pytest.mark.parametrize("C_,N,H,W,norm", [(16, 2, 16, 24, True), (32, 1, 8, 72, True), (64, 1, 8, 8, False), (16, 1, 4, 260, False)])
-def test_f16_local_attention(C_, N, H, W, norm):
+@pytest.mark.parametrize("reg", ["1", "0"])
+@pytest.mark.parametrize("C_,N,H,W,norm", [(16, 2, 16, 24, True), (32, 1, 8, 72, True), (64, 1, 8, 8, False), (16, 1, 4, 260, False),
+                                           # more windows than persistent waves: every wave of the register-resident kernel walks several
+                                           (64, 2, 128, 192, True), (32, 3, 192, 256, False), (16, 2, 256, 320, True)])
+def test_f16_local_attention(C_, N, H, W, norm, reg, monkeypatch):
+    """reg = 1: attn_f16r_kernel (register-resident chains, the default); 0: attn_f16_kernel (LDS tiles)."""
+    monkeypatch.setenv("MSTG_F16_ATTN_REG", reg)
     from mstg_hip.infer import _PackedAttention
     from oracle import restatement as R
     import enhanced_generator as eg
