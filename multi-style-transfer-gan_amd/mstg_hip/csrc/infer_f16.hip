@@ -1453,11 +1453,17 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void attn_f16r_kernel(const h
         }
     };
     Walk fw{w0 / (nwx * nwy), (w0 / nwx) % nwy, w0 % nwx}, pw = fw;
+    // address = wave-uniform window offset (scalar registers) + this lane's constant offset inside a window: no vector arithmetic per window
+    const unsigned lane_off = (unsigned)(((i >> 2) * W + (i & 3)) * C + 4 * g);
+    auto win_off = [&](const Walk& c) -> size_t { return (((size_t)c.n * H + 4 * c.wy) * W + 4 * c.wx) * C; };
     auto fetch = [&](h16x4v (&t)[NB], const Walk& c) {
-        const h16* p = x + (((size_t)c.n * H + 4 * c.wy + (i >> 2)) * W + 4 * c.wx + (i & 3)) * C + 4 * g;
+        const h16* p = x + win_off(c) + lane_off;
 #pragma unroll
         for (int h = 0; h < NB; ++h) t[h] = *reinterpret_cast<const h16x4v*>(p + 16 * h);
     };
+    // normalise-on-load constants of the current image: (x - mean) * rstd = x * sc + nb for this lane's 4 channels per fragment
+    f32x4 sc[NB], nbv[NB];
+    int stats_n = -1;
     // DEPTH windows are fetched as a group while the previous group is computed.  Measured: 4 instead of 1 changes nothing at C = 16 and
     // costs 12 % at C = 32 (a wave per SIMD less) -- at 155 / 240 VALU instructions per window against 6 / 24 MFMAs the kernel is bound
     // by the vector pipe (row sums of the two F.normalize, conversions, softmax), not by loads in flight.
@@ -1483,15 +1489,20 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void attn_f16r_kernel(const h
         pw.next(nwx, nwy);
         h16x4v xa[NB];
         if (in_stats) {  // (x - mean) * rstd, ReLU, as attn_f16_kernel applies it while staging: fp32 arithmetic, one rounding to fp16
+            if (C == 64 || cn != stats_n) {  // wave-uniform: a wave's windows are contiguous, the image changes rarely (C = 64 has no
+                stats_n = cn;                // registers to keep the constants across windows: re-read per window there)
 #pragma unroll
-            for (int h = 0; h < NB; ++h) {
-                const float* st = in_stats + ((size_t)cn * C + 16 * h + 4 * g) * 2;
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1 = *reinterpret_cast<const f32x4*>(st + 4);
-                xa[h][0] = (h16)fmaxf(fmaf((float)cur[d][h][0], s0[1], -s0[0] * s0[1]), 0.f);
-                xa[h][1] = (h16)fmaxf(fmaf((float)cur[d][h][1], s0[3], -s0[2] * s0[3]), 0.f);
-                xa[h][2] = (h16)fmaxf(fmaf((float)cur[d][h][2], s1[1], -s1[0] * s1[1]), 0.f);
-                xa[h][3] = (h16)fmaxf(fmaf((float)cur[d][h][3], s1[3], -s1[2] * s1[3]), 0.f);
+                for (int h = 0; h < NB; ++h) {
+                    const float* st = in_stats + ((size_t)cn * C + 16 * h + 4 * g) * 2;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(st), s1 = *reinterpret_cast<const f32x4*>(st + 4);
+                    sc[h] = f32x4{s0[1], s0[3], s1[1], s1[3]};
+                    nbv[h] = f32x4{-s0[0] * s0[1], -s0[2] * s0[3], -s1[0] * s1[1], -s1[2] * s1[3]};
+                }
             }
+#pragma unroll
+            for (int h = 0; h < NB; ++h)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) xa[h][c] = (h16)fmaxf(fmaf((float)cur[d][h][c], sc[h][c], nbv[h][c]), 0.f);
         } else {
 #pragma unroll
             for (int h = 0; h < NB; ++h) xa[h] = cur[d][h];
@@ -1555,7 +1566,7 @@ __global__ __launch_bounds__(256, C == 64 ? 2 : 3) void attn_f16r_kernel(const h
             for (int m = 0; m < NB; ++m) o = mfma16h(pt[m][n1], vh[m], o);
             oh[n1] = cvt4(o);
         }
-        h16* yp = y + (((size_t)cn * H + 4 * cwy + (i >> 2)) * W + 4 * cwx + (i & 3)) * C + 4 * g;
+        h16* yp = y + (((size_t)cn * H + 4 * cwy) * W + 4 * cwx) * C + lane_off;
 #pragma unroll
         for (int cf = 0; cf < NB; ++cf) {
             f32x4 acc = bp[cf];
