@@ -113,14 +113,15 @@ struct NormQ {
 // window tile L(ci|p): lane (i = pixel, g) <- 16 bytes at channels 16h + 4g of its pixel
 template <int C>
 __device__ __forceinline__ void fetch_cp(f32x4 (&t)[C / 16], const float* __restrict__ src, int H, int W, int n, int wy, int wx, int i, int g) {
-    const float* p = src + (((size_t)n * H + 4 * wy + (i >> 2)) * W + 4 * wx + (i & 3)) * C + 4 * g;
+    // wave-uniform window offset (scalar arithmetic) + the lane's constant offset inside a window (loop-invariant)
+    const float* p = src + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(((i >> 2) * W + (i & 3)) * C + 4 * g);
 #pragma unroll
     for (int h = 0; h < C / 16; ++h) t[h] = *reinterpret_cast<const f32x4*>(p + 16 * h);
 }
 // window tile L(p|c): lane (i = channel, g) <- register r = pixel 4g + r (window row g, column r), channel 16f + i
 template <int C>
 __device__ __forceinline__ void fetch_pc(f32x4 (&t)[C / 16], const float* __restrict__ src, int H, int W, int n, int wy, int wx, int i, int g) {
-    const float* p = src + (((size_t)n * H + 4 * wy + g) * W + 4 * wx) * C + i;
+    const float* p = src + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(g * W * C + i);
 #pragma unroll
     for (int f = 0; f < C / 16; ++f)
 #pragma unroll
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, fwd_waves_per_simd<C>()) void attn_reg_fwd_ker
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int cf = 0; cf < NF; ++cf) yt[cf] = mfma16(wpr[cf][n1][r], ot[n1][r], yt[cf]);
-        float* dst = y + (((size_t)n * H + 4 * wy + (i >> 2)) * W + 4 * wx + (i & 3)) * C + 4 * g;
+        float* dst = y + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(((i >> 2) * W + (i & 3)) * C + 4 * g);
 #pragma unroll
         for (int cf = 0; cf < NF; ++cf) *reinterpret_cast<f32x4*>(dst + 16 * cf) = yt[cf];
     }
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64 * WAVES, C == 16 ? 4 : WAVES / 4) void attn_reg_
                 for (int cf = 0; cf < NF; ++cf) dXt[cf] = mfma16(w2[cf][r], dqkv[jf][r], dXt[cf]);
         }
         {
-            float* dst = dx + (((size_t)n * H + 4 * wy + (i >> 2)) * W + 4 * wx + (i & 3)) * C + 4 * g;
+            float* dst = dx + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(((i >> 2) * W + (i & 3)) * C + 4 * g);
 #pragma unroll
             for (int cf = 0; cf < NF; ++cf) *reinterpret_cast<f32x4*>(dst + 16 * cf) = dXt[cf];
         }
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void attn_big_fwd_kernel(const float* __res
 #pragma unroll
                 for (int cf = 0; cf < NF; ++cf) yt[cf] = mfma16(wv[cf][r], ot[n1][r], yt[cf]);
         }
-        float* dst = y + (((size_t)n * H + 4 * wy + (i >> 2)) * W + 4 * wx + (i & 3)) * C + 4 * g;
+        float* dst = y + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(((i >> 2) * W + (i & 3)) * C + 4 * g);
 #pragma unroll
         for (int cf = 0; cf < NF; ++cf) *reinterpret_cast<f32x4*>(dst + 16 * cf) = yt[cf];
     }
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(256, 1) void attn_big_bwd_kernel(const float* __res
                 __builtin_amdgcn_sched_barrier(0);
             }
             {
-                float* dst = dx + (((size_t)n * H + 4 * wy + g) * W + 4 * wx) * C + i;
+                float* dst = dx + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(g * W * C + i);
 #pragma unroll
                 for (int cf = 0; cf < NF; ++cf)
 #pragma unroll
@@ -1163,7 +1164,7 @@ __global__ __launch_bounds__(256, 1) void attn_big_bwd_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < FOWN; ++k) {  // dY[4g + r][16 (wave + 4k) + i]
                 const int f = wave + WAVES * k;
-                const float* p = dy + (((size_t)n * H + 4 * wy + g) * W + 4 * wx) * C + 16 * (f < NF ? f : 0) + i;
+                const float* p = dy + (((size_t)n * H + 4 * wy) * W + 4 * wx) * C + (unsigned)(g * W * C + 16 * (f < NF ? f : 0) + i);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dy4[ww][k][r] = p[r * C];
             }
