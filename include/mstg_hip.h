@@ -342,6 +342,12 @@ int mstg_f16_conv_pack(const mstg_f16_conv_desc* d, const float* w0, const float
 size_t mstg_f16_conv_partial_bytes(const mstg_f16_conv_desc* d); /* workspace needed when out_stats != NULL */
 int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats /*nullable*/, void* y,
                       float* out_stats /*nullable*/, void* workspace, size_t workspace_bytes, void* stream);
+/* The same layer reading relu((x - mean) * rstd) + residual instead of x: a MultiScaleBlock's closing norm + ReLU + `+ x`
+ * (enhanced_generator.py:84) formed while the NEXT layer (:106, :121, :128, :137) stages its input, bit for bit the values
+ * mstg_f16_norm_residual would have written.  residual (nullable: then exactly mstg_f16_conv_fwd) needs in_stats and an NHWC source. */
+int mstg_f16_conv_fwd_res(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats,
+                          const void* residual /*nullable*/, void* y, float* out_stats /*nullable*/, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* y = relu((x - mean) * rstd) + residual (nullable): the fusion conv's norm and the block's `+ x` (:84); NHWC fp16 */
 int mstg_f16_norm_residual(const void* x, const void* residual, const float* stats, void* y, int N, int HW, int C, void* stream);
 /* whole LocalAttention module (:13-47) on NHWC fp16, C in {16,32,64}; in_stats (nullable) = normalise + ReLU on load of x;

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mstg_f16_conv_pack": (_i, [_hp] + [_fp] * 8 + [_vp, _sz, _vp]),
     "mstg_f16_conv_partial_bytes": (_sz, [_hp]),
     "mstg_f16_conv_fwd": (_i, [_hp, _vp, _vp, _fp, _vp, _fp, _vp, _sz, _vp]),
+    "mstg_f16_conv_fwd_res": (_i, [_hp, _vp, _vp, _fp, _vp, _vp, _fp, _vp, _sz, _vp]),
     "mstg_f16_norm_residual": (_i, [_vp, _vp, _fp, _vp, _i, _i, _i, _vp]),
     "mstg_f16_attn_plan_bytes": (_sz, [_i]),
     "mstg_f16_attn_pack": (_i, [_fp, _fp, _fp, _fp, _i, _vp, _sz, _vp]),

@@ -64,6 +64,7 @@ struct F16Plan {
 
 struct F16ConvArgs {
     const void* x;          // NHWC fp16, or NCHW fp32 (src = 1)
+    const h16* res;         // src = 2: the layer's input is relu((x - mean) * rstd) + res, formed while staging (both NHWC fp16)
     h16* y;                 // NHWC fp16, or NCHW fp16 (dst = 1)
     const h16* wpk;         // [step][frag][lane][8]
     const float* bias;      // [16 * NF]
@@ -148,7 +149,8 @@ struct FalseT { static constexpr bool value = false; };
 
 template <int NPF, int SRC>
 struct PatchRegs {
-    h16x8 v[SRC == 0 ? NPF : 1];
+    h16x8 v[SRC != 1 ? NPF : 1];
+    h16x8 r2[SRC == 2 ? NPF : 1];  // the residual operand of the same patch elements
     f32x4 f[SRC == 1 ? NPF : 1];
     unsigned okmask;
 };
@@ -165,7 +167,7 @@ struct PatchGeom {
 template <int NPF, int SRC>
 __device__ __forceinline__ void patch_geom(const F16ConvArgs& a, const F16Plan& p, int tid, PatchGeom<NPF>& Gm) {
     Gm.vmask = 0;
-    const int oct = SRC == 0 ? (a.Cin >> 3) : 1, o = tid & (oct - 1), sh = oct == 1 ? 0 : (oct == 2 ? 1 : (oct == 4 ? 2 : 3));
+    const int oct = SRC != 1 ? (a.Cin >> 3) : 1, o = tid & (oct - 1), sh = oct == 1 ? 0 : (oct == 2 ? 1 : (oct == 4 ? 2 : 3));
     const int total = p.PH * p.PW * oct;
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
@@ -173,7 +175,7 @@ __device__ __forceinline__ void patch_geom(const F16ConvArgs& a, const F16Plan& 
         const int pix = e >> sh;
         const int r = (int)__umulhi((unsigned)pix, p.m_pw), c = pix - r * p.PW;
         if (e < total) Gm.vmask |= 1u << k;
-        if (SRC == 0) {
+        if (SRC != 1) {
             Gm.rel[k] = (unsigned)(((r * a.W + c) * a.Cin + 8 * o) * 2);
         } else {
             Gm.rel[k] = (unsigned)((r * a.W + c) * 4);
@@ -192,13 +194,19 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
     const int ty = a.tiles_x == 1 ? tt : (int)__umulhi((unsigned)tt, p.m_tx), tx = tt - ty * a.tiles_x;
     const int sy0 = ty * TH * p.stride + p.oy0, sx0 = tx * p.tstep * p.stride + p.ox0;
     const bool interior = sy0 >= 0 && sx0 >= 0 && sy0 + p.PH <= a.H && sx0 + p.PW <= a.W;  // uniform
-    if (SRC == 0) {
+    if (SRC != 1) {
         const char* img = reinterpret_cast<const char*>(a.x) + (size_t)n * a.H * a.W * a.Cin * 2;
+        const char* rimg = reinterpret_cast<const char*>(a.res) + (size_t)n * a.H * a.W * a.Cin * 2;
         if (interior) {
-            const char* org = img + ((size_t)sy0 * a.W + sx0) * a.Cin * 2;
+            const size_t oo = ((size_t)sy0 * a.W + sx0) * a.Cin * 2;
+            const char* org = img + oo;
             R.okmask = Gm.vmask;
 #pragma unroll
             for (int k = 0; k < NPF; ++k) R.v[k] = *reinterpret_cast<const h16x8*>(org + (((Gm.vmask >> k) & 1) ? Gm.rel[k] : 0u));
+            if (SRC == 2) {
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) R.r2[k] = *reinterpret_cast<const h16x8*>(rimg + oo + (((Gm.vmask >> k) & 1) ? Gm.rel[k] : 0u));
+            }
         } else {
             R.okmask = 0;
             const long org = ((long)sy0 * a.W + sx0) * a.Cin * 2;
@@ -211,6 +219,7 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
                 const bool ok = ((Gm.vmask >> k) & 1) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 R.okmask |= (unsigned)ok << k;
                 R.v[k] = *reinterpret_cast<const h16x8*>(img + (ok ? org + (long)Gm.rel[k] : 0L));
+                if (SRC == 2) R.r2[k] = *reinterpret_cast<const h16x8*>(rimg + (ok ? org + (long)Gm.rel[k] : 0L));
             }
         }
     } else {
@@ -239,9 +248,9 @@ __device__ __forceinline__ void patch_fetch(const F16ConvArgs& a, const F16Plan&
 template <int NPF, int SRC>
 __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan& p, int n, int tid, const PatchGeom<NPF>& Gm,
                                              const PatchRegs<NPF, SRC>& R, unsigned char* patch) {
-    if (SRC == 0) {
+    if (SRC != 1) {
         const int oct = a.Cin >> 3, o = tid & (oct - 1), sh = oct == 2 ? 1 : (oct == 4 ? 2 : 3);
-        const bool norm = a.in_stats != nullptr;
+        const bool norm = SRC == 2 || a.in_stats != nullptr;  // src = 2 always carries statistics (checked by the host)
         float sc[8], nb[8];  // (x - mean) * rstd = x * sc + nb
         if (norm) {
             const float* st = a.in_stats + ((size_t)n * a.Cin + 8 * o) * 2;
@@ -252,7 +261,11 @@ __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan
         for (int k = 0; k < NPF; ++k) {
             if ((Gm.vmask >> k) & 1) {
                 h16x8 w = R.v[k];
-                if (norm) {
+                if (SRC == 2) {  // the arithmetic of f16_norm_residual_kernel, so that folding the pass changes no bit
+                    const h16x8 rr = R.r2[k];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) w[c] = (h16)(fmaxf(fmaf((float)w[c], sc[c], nb[c]), 0.f) + (float)rr[c]);
+                } else if (norm) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) w[c] = (h16)fmaxf(fmaf((float)w[c], sc[c], nb[c]), 0.f);
                 }
@@ -274,8 +287,9 @@ __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan
 }
 
 // register budget: the light single-fragment kernels want four workgroups per CU (<= 128 VGPRs); the others are LDS-bound to 1-2
+// (the residual operand of src = 2 must not cost the light kernels their third workgroup per CU: <= 168 registers)
 template <int RPW, int NF, int SRC, int DST, int NPF, bool WLDS>
-__global__ __launch_bounds__(256) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
+__global__ __launch_bounds__(256, (SRC == 2 && NF == 1 && NPF <= 4) ? 3 : 1) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 4 * RPW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -722,10 +736,10 @@ __global__ __launch_bounds__(256) void f16_norm_residual_kernel(const h16* __res
                                                                 int blocks_per_image) {
     const int n = blockIdx.x / blocks_per_image, b = blockIdx.x - n * blocks_per_image;
     const int oct = C >> 3, o = threadIdx.x & (oct - 1);
-    float mu[8], rs[8];
+    float sc[8], nb[8];  // (x - mean) * rstd = x * sc + nb: the form (and the bits) of the consumers' normalise-on-load
     const float* st = stats + ((size_t)n * C + 8 * o) * 2;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { mu[c] = st[2 * c]; rs[c] = st[2 * c + 1]; }
+    for (int c = 0; c < 8; ++c) { sc[c] = st[2 * c + 1]; nb[c] = -st[2 * c] * st[2 * c + 1]; }
     const size_t total = HW * oct;  // 16-byte chunks of this image
     const size_t base = (size_t)n * total;
     const h16x8* xv = reinterpret_cast<const h16x8*>(x) + base;
@@ -737,10 +751,7 @@ __global__ __launch_bounds__(256) void f16_norm_residual_kernel(const h16* __res
         if (rv) r = rv[e];
         h16x8 w;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float f = ((float)a[c] - mu[c]) * rs[c];
-            w[c] = (h16)((f > 0.f ? f : 0.f) + (float)r[c]);
-        }
+        for (int c = 0; c < 8; ++c) w[c] = (h16)(fmaxf(fmaf((float)a[c], sc[c], nb[c]), 0.f) + (float)r[c]);
         yv[e] = w;
     }
 }
@@ -1011,6 +1022,8 @@ static int launch_conv(const F16ConvArgs& a, const F16Plan& p, int src, int dst,
     if (src == 0 && dst == 0) MSTG_F16_LAUNCH(0, 0);
     else if (src == 1 && dst == 0) MSTG_F16_LAUNCH(1, 0);
     else if (src == 0 && dst == 1) MSTG_F16_LAUNCH(0, 1);
+    else if (src == 2 && dst == 0) MSTG_F16_LAUNCH(2, 0);
+    else if (src == 2 && dst == 1) MSTG_F16_LAUNCH(2, 1);
     else return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: NCHW source and destination in one layer");
 #undef MSTG_F16_LAUNCH
     MSTG_CHECK_LAUNCH("conv_f16_kernel");
@@ -1070,7 +1083,14 @@ extern "C" size_t mstg_f16_conv_partial_bytes(const mstg_f16_conv_desc* d) {
 
 extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats, void* y,
                                  float* out_stats, void* workspace, size_t workspace_bytes, void* stream) {
+    return mstg_f16_conv_fwd_res(d, blob, x, in_stats, nullptr, y, out_stats, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mstg_f16_conv_fwd_res(const mstg_f16_conv_desc* d, const void* blob, const void* x, const float* in_stats,
+                                     const void* residual, void* y, float* out_stats, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (!d || !blob || !x || !y) return fail_arg(MSTG_E_BADARG, "f16 conv: null pointer");
+    if (residual && (!in_stats || d->src_nchw_f32)) return fail_arg(MSTG_E_BADARG, "f16 conv: a residual operand needs NHWC input and its statistics");
     F16Plan p;
     PackTable* pt = new PackTable;
     const int rc = build_plan(d, p, *pt);
@@ -1079,6 +1099,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     if (in_stats && d->src_nchw_f32) return fail_arg(MSTG_E_UNSUPPORTED, "f16 conv: no normalise-on-load for the image source");
     F16ConvArgs a;
     a.x = x; a.y = (h16*)y;
+    a.res = (const h16*)residual;
     a.bias = (const float*)blob;
     a.wpk = (const h16*)((const char*)blob + 256);
     a.in_stats = in_stats;
@@ -1112,7 +1133,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
     hipStream_t st = (hipStream_t)stream;
     {   // 1x1: fragments straight from global memory, no LDS patch (conv1x1_f16_kernel)
         const char* e = getenv("MSTG_F16_DIRECT");
-        const bool direct = d->kind == 0 && d->K == 1 && d->stride == 1 && !d->src_nchw_f32 && !d->dst_nchw && d->act == MSTG_ACT_NONE &&
+        const bool direct = !residual && d->kind == 0 && d->K == 1 && d->stride == 1 && !d->src_nchw_f32 && !d->dst_nchw && d->act == MSTG_ACT_NONE &&
                             (d->Cout & 15) == 0 && p.TH == 16 && !(e && e[0] == '0');
         if (direct) {
             const int KS = (d->Cin + 31) / 32;
@@ -1150,7 +1171,7 @@ extern "C" int mstg_f16_conv_fwd(const mstg_f16_conv_desc* d, const void* blob, 
             }
         }
     }
-    const int src = d->src_nchw_f32 ? 1 : 0, dst = d->dst_nchw ? 1 : 0;
+    const int src = d->src_nchw_f32 ? 1 : (residual ? 2 : 0), dst = d->dst_nchw ? 1 : 0;
     int lrc;
     if (p.TH == 32) {
         lrc = launch_conv_npf<8, 1>(a, p, src, dst, lds, grid, st, &launched);

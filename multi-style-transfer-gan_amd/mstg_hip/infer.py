@@ -14,6 +14,7 @@ batch_process_images.py:95, advanced_transform.py:12).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -59,8 +60,9 @@ class _PackedConv:
         return _desc(self.kind, N, H, W, self.Cin, Ho, Wo, self.Cout, self.K, self.stride, self.pad, 1, self.src_nchw_f32,
                      self.dst_nchw, self.act)
 
-    def __call__(self, x, in_stats=None, want_stats=False):
-        """x: NHWC fp16 (N,H,W,Cin) or the NCHW fp32 image -> (y, out_stats or None)."""
+    def __call__(self, x, in_stats=None, want_stats=False, residual=None):
+        """x: NHWC fp16 (N,H,W,Cin) or the NCHW fp32 image -> (y, out_stats or None).  ``residual`` (NHWC fp16 like x, needs
+        ``in_stats``): the layer reads relu(IN(x)) + residual, formed while it stages its input."""
         lib = _lib.load()
         if self.src_nchw_f32:
             N, _, H, W = x.shape
@@ -79,13 +81,18 @@ class _PackedConv:
         cout_eff = self.Cout // 4 if self.kind == 2 else self.Cout
         pix = N * d.Ho * d.Wo / (4 if self.kind == 1 else 1)
         flops = 2.0 * pix * self.Cin * cout_eff * taps
-        nbytes = x.numel() * x.element_size() + y.numel() * 2
+        nbytes = x.numel() * x.element_size() * (2 if residual is not None else 1) + y.numel() * 2
         name = {0: "conv_f16_kernel", 1: "conv_f16_kernel<convT>", 2: "conv_f16_kernel<msblock>"}[self.kind]
         if self.kind == 0 and self.K == 1 and self.stride == 1 and not self.src_nchw_f32 and not self.dst_nchw:
             name = "conv1x1_f16_kernel"  # the LDS-free streaming variant (unless MSTG_F16_DIRECT=0)
+        if residual is not None:
+            if residual.shape != x.shape or residual.dtype != torch.float16 or not residual.is_contiguous() or in_stats is None:
+                raise RuntimeError("mstg_hip fp16 conv: the residual operand must match x (NHWC fp16) and comes with in_stats")
+            name += "+res"
         _timed(name, flops, nbytes, lambda: _lib.check(
-            lib.mstg_f16_conv_fwd(C.byref(d), _p(self.blob), _p(x), _p(in_stats), _p(y), _p(stats), _p(ws), wsb, _stream()),
-            "mstg_f16_conv_fwd"), f"k{self.kind} N{N} {H}x{W} {self.Cin}->{self.Cout} k{self.K} s{self.stride}")
+            lib.mstg_f16_conv_fwd_res(C.byref(d), _p(self.blob), _p(x), _p(in_stats), _p(residual), _p(y), _p(stats), _p(ws), wsb,
+                                      _stream()),
+            "mstg_f16_conv_fwd_res"), f"k{self.kind} N{N} {H}x{W} {self.Cin}->{self.Cout} k{self.K} s{self.stride}")
         return y, stats
 
 
@@ -161,13 +168,21 @@ class HalfGeneratorPlan:
             raise RuntimeError("mstg_hip: input must live on the GPU (this package has no CPU path)")
         x = x.float().contiguous()
         h, stats = self.stem(x, want_stats=True)   # pre-norm stem output; its IN + ReLU is applied by down1's conv on load
+        # A stage's closing relu(IN(f)) + a is formed by the NEXT layer while it stages its input (same arithmetic, same bits as
+        # f16_norm_residual_kernel; MSTG_F16_FOLD_RESIDUAL=0 keeps the pass).  The pass stays where somebody needs the tensor
+        # itself: parity taps, and the stage in front of the transformer blocks.
+        fold = taps is None and os.environ.get("MSTG_F16_FOLD_RESIDUAL", "1") != "0"
+        res = None
         for si, (first, attn, branches, fusion) in enumerate(self.stages):
-            c, st_c = first(h, in_stats=stats, want_stats=True)
+            c, st_c = first(h, in_stats=stats, want_stats=True, residual=res)
             a = attn(c, in_stats=st_c)              # IN + ReLU of the stage's first norm: on load
             cat, st_cat = branches(a, want_stats=True)
             f, st_f = fusion(cat, in_stats=st_cat, want_stats=True)
+            if fold and not (si == 1 and self.blocks):
+                h, stats, res = f, st_f, a          # the consumer forms relu(IN(f)) + a
+                continue
             h = norm_residual(f, a, st_f)           # relu(IN(f)) + a
-            stats = None
+            stats = res = None
             if taps is not None:
                 taps[("down1", "down2", "up1", "up2")[si]] = h
             if si == 1 and self.blocks:             # enhanced_generator.py:216-225: style vector, tokens, blocks, back
@@ -180,4 +195,4 @@ class HalfGeneratorPlan:
                 h = tokens.reshape(N, H4, W4, C4).half()
         if taps is not None:
             taps["pre_tanh"] = self.head_pre(h)[0]
-        return self.head(h)[0]
+        return self.head(h, in_stats=stats, residual=res)[0]

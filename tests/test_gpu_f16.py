@@ -240,6 +240,48 @@ def test_f16_generator_contract():
     assert torch.equal(y16in, m.half_inference()._half().forward(x.half().float()))
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 48, 80), (3, 3, 112, 16), (1, 3, 256, 256)])
+def test_f16_residual_folded_into_next_layer_is_bit_identical(shape, monkeypatch):
+    """A stage's closing relu(IN(fusion)) + x (enhanced_generator.py:84) is formed by the next layer (:106, :121, :128, :137)
+    while it stages its input; MSTG_F16_FOLD_RESIDUAL=0 keeps the separate pass.  Same arithmetic, same rounding: equal bits,
+    border tiles and batch > 1 included."""
+    from oracle import restatement as R
+    m, _ = _pair(441)
+    x = R.make_input(shape, 442).to(DEV)
+    m.half_inference()
+    with torch.no_grad():
+        y_fold = m(x)
+        monkeypatch.setenv("MSTG_F16_FOLD_RESIDUAL", "0")
+        y_pass = m(x)
+        y_taps = m.forward_taps(x, {})
+    assert torch.isfinite(y_fold).all() and torch.equal(y_fold, y_pass) and torch.equal(y_fold, y_taps)
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,hw", [(0, 32, 64, 4, 2, 1, (40, 24)), (1, 64, 32, 4, 2, 1, (12, 20)),
+                                                    (1, 32, 16, 4, 2, 1, (16, 16)), (0, 16, 16, 3, 1, 1, (33, 17))])
+def test_f16_conv_residual_operand_vs_separate_pass(kind, cin, cout, k, s, p, hw):
+    """mstg_f16_conv_fwd_res against mstg_f16_norm_residual followed by mstg_f16_conv_fwd on one layer (ragged sizes)."""
+    from mstg_hip import infer
+    g = torch.Generator().manual_seed(451)
+    N, (H, W) = 2, hw
+    wshape = (cin, cout, k, k) if kind == 1 else (cout, cin, k, k)
+    w = (torch.randn(wshape, generator=g) * 0.1).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    f = torch.randn((N, H, W, cin), generator=g).half().to(DEV)
+    a = torch.randn((N, H, W, cin), generator=g).half().to(DEV)
+    ff = f.float()
+    mean = ff.mean(dim=(1, 2))
+    rstd = (ff.var(dim=(1, 2), unbiased=False) + 1e-5).rsqrt()
+    stats = torch.stack([mean, rstd], dim=-1).contiguous()
+    conv = infer._PackedConv(kind, [w], [b], cin, cout, k, s, p)
+    y_fold, st_fold = conv(f, in_stats=stats, want_stats=True, residual=a)
+    h = infer.norm_residual(f, a, stats)
+    y_pass, st_pass = conv(h, want_stats=True)
+    assert torch.equal(y_fold, y_pass) and torch.equal(st_fold, st_pass)
+    with pytest.raises(RuntimeError):
+        conv(f, residual=a)  # a residual operand comes with the statistics of x
+
+
 def test_config5_forward_1024_fp16():
     """BASELINE config #5 itself: 1024x1024, fp16.  Batch 1 against the fp32 path; batch 64 (the benchmarked shape; activations of
     2.1 GB, > 2^31 elements): finite, and samples 0 / 63 equal the batch-1 results of the same images."""
