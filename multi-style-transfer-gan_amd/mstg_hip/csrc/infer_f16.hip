@@ -287,9 +287,10 @@ __device__ __forceinline__ void patch_commit(const F16ConvArgs& a, const F16Plan
 }
 
 // register budget: the light single-fragment kernels want four workgroups per CU (<= 128 VGPRs); the others are LDS-bound to 1-2
-// (the residual operand of src = 2 must not cost the light kernels their third workgroup per CU: <= 168 registers)
+// (three workgroups per CU for the light kernels, <= 168 registers: left alone the compiler takes 160-212, told so it needs 97-161
+// without spilling; the variants that would spill keep the default)
 template <int RPW, int NF, int SRC, int DST, int NPF, bool WLDS>
-__global__ __launch_bounds__(256, (SRC == 2 && NF == 1 && NPF <= 4) ? 3 : 1) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
+__global__ __launch_bounds__(256, (NF == 1 && RPW <= 4 && NPF <= (SRC == 2 ? 4 : 6)) ? 3 : ((NF == 2 && NPF <= 6 && !(RPW == 4 && SRC == 2 && NPF == 6)) || (NF == 4 && RPW == 2 && NPF <= 4 && SRC != 2)) ? 2 : 1) void conv_f16_kernel(const F16ConvArgs a, const F16Plan p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TH = 4 * RPW;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
