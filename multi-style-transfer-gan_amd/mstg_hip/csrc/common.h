@@ -61,7 +61,7 @@ enum EnvKnob {
     ENV_ATTN_BLK4, ENV_ATTN_BLK64, ENV_WGRAD_1X1, ENV_WGRAD_TS_MAXCH, ENV_WGRAD_PLAIN, ENV_WGRAD_OLD, ENV_NO_DPACK, ENV_IGEMM,
     ENV_STREAM, ENV_PF, ENV_WGLOB, ENV_HEAVY_PER_CU, ENV_DBG, ENV_DBG_LDS_KB, ENV_MS_WGRAD_PACKED, ENV_MS_FWD4, ENV_NO_PACK_CACHE,
     ENV_P32, ENV_P32_TH, ENV_P32_WLDS, ENV_P32_DBG, ENV_P32_OCC, ENV_ATTN_REG, ENV_NFW_ADAPT, ENV_BSUMS_ALL, ENV_ATTN_BIG32, ENV_NORM_WGS,
-    ENV_COUNT
+    ENV_CONV_IMG, ENV_COUNT
 };
 const char* env_get(EnvKnob k);  // value as of the last refresh, nullptr when unset (runtime.hip)
 

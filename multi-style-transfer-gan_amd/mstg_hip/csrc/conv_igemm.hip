@@ -1055,6 +1055,7 @@ size_t igemm_workspace_bytes(IGemmArgs a) {
 }
 
 int launch_igemm(IGemmArgs& a, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (img_dgrad_eligible(a)) return launch_img_dgrad(a, st);  // 3-channel image gradient of a 4x4 stride-2 layer: no MFMA tile to fill
     if (p32_eligible(a)) return launch_p32(a, workspace, workspace_bytes, st);  // 4x4 stride-2 family at 16 / 32 / 64 channels
     a.dbg = 0;
     IGemmPlan p;
@@ -1281,6 +1282,7 @@ const char* igemm_kernel_name(const mstg_conv_desc* d, int pass) {
     if (check_desc(d)) return "";
     if (pass == 0) fill_fwd_args(d, a);
     else if (fill_dgrad_args(d, a)) return "";
+    if (img_dgrad_eligible(a)) { snprintf(name, sizeof(name), "conv_img_dgrad_kernel<%d>", a.Co); return name; }
     if (plan_igemm(a, p)) return "";
     if (p32_eligible(a)) return p32_kernel_name(a);
     if (p.stream) snprintf(name, sizeof(name), "igemm_stream_kernel<%d, %d, %d, %d>", p.V, p.nfw, p.pf, p.src);

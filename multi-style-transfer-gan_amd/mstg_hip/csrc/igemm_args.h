@@ -47,4 +47,8 @@ int launch_p32_bsums(const IGemmArgs& a, const float* aux, const float* aux_stat
                      hipStream_t st);
 const char* p32_kernel_name(const IGemmArgs& a);
 
+// conv_img.hip: input gradient of the discriminator's image-side layer, Conv2d(3, C, 4, 2, 1) on the NCHW image, on the vector pipe
+bool img_dgrad_eligible(const IGemmArgs& a);
+int launch_img_dgrad(const IGemmArgs& a, hipStream_t st);
+
 }  // namespace mstg

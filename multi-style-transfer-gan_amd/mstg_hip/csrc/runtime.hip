@@ -17,7 +17,8 @@ thread_local bool t_ws_packed = false;
 static const char* const kEnvNames[ENV_COUNT] = {
     "MSTG_ATTN_BLK4", "MSTG_ATTN_BLK64", "MSTG_WGRAD_1X1", "MSTG_WGRAD_TS_MAXCH", "MSTG_WGRAD_PLAIN", "MSTG_WGRAD_OLD", "MSTG_NO_DPACK",
     "MSTG_IGEMM", "MSTG_STREAM", "MSTG_PF", "MSTG_WGLOB", "MSTG_HEAVY_PER_CU", "MSTG_DBG", "MSTG_DBG_LDS_KB", "MSTG_MS_WGRAD_PACKED",
-    "MSTG_MS_FWD4", "MSTG_NO_PACK_CACHE", "MSTG_P32", "MSTG_P32_TH", "MSTG_P32_WLDS", "MSTG_P32_DBG", "MSTG_P32_OCC", "MSTG_ATTN_REG", "MSTG_NFW_ADAPT", "MSTG_BSUMS_ALL", "MSTG_ATTN_BIG32", "MSTG_NORM_WGS"};
+    "MSTG_MS_FWD4", "MSTG_NO_PACK_CACHE", "MSTG_P32", "MSTG_P32_TH", "MSTG_P32_WLDS", "MSTG_P32_DBG", "MSTG_P32_OCC", "MSTG_ATTN_REG", "MSTG_NFW_ADAPT", "MSTG_BSUMS_ALL", "MSTG_ATTN_BIG32", "MSTG_NORM_WGS",
+    "MSTG_CONV_IMG"};
 
 struct EnvCache {
     char val[ENV_COUNT][32];

@@ -97,6 +97,12 @@ CONV_CASES = [
     ("w7 stem7x7 3->16 nchw-in 256x256 N4", 4, 256, 256, 3, 16, 7, 1, 3, 1, 0, 1, 0, 0),
     ("w7 head7x7 16->3 nchw-out tanh 256x256 N4", 4, 256, 256, 16, 3, 7, 1, 3, 1, 0, 0, 1, 3),
     ("w7 stem7x7 1->16 nchw-in 16x16", 2, 16, 16, 1, 16, 7, 1, 3, 1, 0, 1, 0, 0),
+    # the discriminator's image-side layer: its input gradient runs on the vector pipe (conv_img.hip); widths 8 ... 64, ragged, 1-3 channels
+    ("img k4s2 3->16 nchw-in 64x64 N2", 2, 64, 64, 3, 16, 4, 2, 1, 1, 0, 1, 0, 0),
+    ("img k4s2 3->64 nchw-in ragged 36x20 N3", 3, 36, 20, 3, 64, 4, 2, 1, 1, 0, 1, 0, 0),
+    ("img k4s2 3->24 nchw-in 2x2", 2, 2, 2, 3, 24, 4, 2, 1, 1, 0, 1, 0, 0),
+    ("img k4s2 1->16 nchw-in 18x30", 1, 18, 30, 1, 16, 4, 2, 1, 1, 0, 1, 0, 0),
+    ("img k4s2 3->16 nchw-in 256x256 N4", 4, 256, 256, 3, 16, 4, 2, 1, 1, 0, 1, 0, 0),
 ]
 
 
@@ -269,7 +275,7 @@ def test_conv_channel_slices_and_accumulate(N, H, W, ch):
 @pytest.mark.parametrize("env", ["MSTG_MS_UNFUSED=1", "MSTG_MS_WGRAD_PACKED=0", "MSTG_MS_FWD4=0", "MSTG_MS_FWD4=1", "MSTG_MS_FWD4=2", "MSTG_WGLOB=0",
                                  "MSTG_WGRAD_1X1=0", "MSTG_PF=2", "MSTG_NO_DPACK=1", "MSTG_WGRAD_PLAIN=1", "MSTG_ATTN_BLK64=0", "MSTG_ATTN_BLK4=0",
                                  "MSTG_P32=0", "MSTG_P32_TH=4", "MSTG_P32_TH=8", "MSTG_P32_TH=16", "MSTG_P32_WLDS=0", "MSTG_P32_WLDS=1",
-                                 "MSTG_ATTN_REG=0", "MSTG_ATTN_BIG32=1"])
+                                 "MSTG_ATTN_REG=0", "MSTG_ATTN_BIG32=1", "MSTG_CONV_IMG=0"])
 def test_kernel_selection_switches_keep_parity(env, monkeypatch):
     """Every runtime switch of INTEGRATION.md section 3 selects another kernel for the same arithmetic: the fallbacks stay correct."""
     k, v = env.split("=")
@@ -282,6 +288,10 @@ def test_kernel_selection_switches_keep_parity(env, monkeypatch):
         if case[0] in ("head7x7 16->3 nchw-out tanh", "k4s2 16->32", "1x1 16->48", "k3 d1 16->4") or (k.startswith("MSTG_P32") and (
                 case[0].startswith(("p32", "convT", "k4s2", "w7", "stem7x7", "head7x7")))):
             test_conv_fwd_bwd(case)
+    if k == "MSTG_CONV_IMG":  # the image-side 4x4 stride-2 layer back on the MFMA kernels
+        for case in CONV_CASES:
+            if case[0].startswith("img") or "D stem" in case[0]:
+                test_conv_fwd_bwd(case)
     if k == "MSTG_ATTN_BLK64":
         test_window_attention_core(2, 8, 8, 64)
         test_window_attention_core(1, 8, 4, 48)
