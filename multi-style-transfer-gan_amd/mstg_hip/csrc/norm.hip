@@ -49,12 +49,13 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
         if (!BWD) {
             const f32x4 K = *reinterpret_cast<const f32x4*>((batch ? x : xb) + 4 * q);
             int p = p0 + row;
-            for (; p + 3 * rows < p1; p += 4 * rows) {
-                f32x4 v[4];
+            constexpr int PX = 8;  // loads in flight per thread; the additions keep the order p, p + rows, ...
+            for (; p + (PX - 1) * rows < p1; p += PX * rows) {
+                f32x4 v[PX];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(p + k * rows) * C + 4 * q);
+                for (int k = 0; k < PX; ++k) v[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(p + k * rows) * C + 4 * q);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PX; ++k) {
                     const f32x4 w = v[k] - K;
                     s1 += w;
                     s2 += w * w;
@@ -73,15 +74,16 @@ __global__ __launch_bounds__(256) void norm_partial_kernel(const float* __restri
             if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
             const float* dyb = dy + (size_t)n * g.HW * C;
             int p = p0 + row;
-            for (; p + 3 * rows < p1; p += 4 * rows) {
-                f32x4 xv[4], gv[4];
+            constexpr int PX = 8;
+            for (; p + (PX - 1) * rows < p1; p += PX * rows) {
+                f32x4 xv[PX], gv[PX];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PX; ++k) {
                     xv[k] = *reinterpret_cast<const f32x4*>(xb + (size_t)(p + k * rows) * C + 4 * q);
                     gv[k] = *reinterpret_cast<const f32x4*>(dyb + (size_t)(p + k * rows) * C + 4 * q);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PX; ++k) {
                     const f32x4 xh = (xv[k] - mu) * rs;
                     f32x4 gg = gv[k];
 #pragma unroll
@@ -199,16 +201,17 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         const f32x4 A = *reinterpret_cast<const f32x4*>(&sm[4 * q]), B = *reinterpret_cast<const f32x4*>(&sm[C + 4 * q]);
         const f32x4 M = *reinterpret_cast<const f32x4*>(&sm[2 * C + 4 * q]);
         int p = p0 + row;
-        for (; p + 3 * rows < p1; p += 4 * rows) {  // four independent pixels per trip: 4-8 loads in flight per thread
-            f32x4 v[4], r[4];
+        constexpr int PX = 8;  // independent pixels per trip: 8-16 sixteen-byte loads in flight per thread, read-once (non-temporal)
+        for (; p + (PX - 1) * rows < p1; p += PX * rows) {
+            f32x4 v[PX], r[PX];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PX; ++k) {
                 const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
-                v[k] = *reinterpret_cast<const f32x4*>(x + o);
-                if (residual) r[k] = *reinterpret_cast<const f32x4*>(residual + o);
+                v[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + o));
+                if (residual) r[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(residual + o));
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PX; ++k) {
                 const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
                 f32x4 w = (v[k] - M) * A + B;
 #pragma unroll
@@ -231,16 +234,17 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const float* __restrict
         f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
         if (batch) { ga = *reinterpret_cast<const f32x4*>(gamma + 4 * q); be = *reinterpret_cast<const f32x4*>(beta + 4 * q); }
         int p = p0 + row;
-        for (; p + 3 * rows < p1; p += 4 * rows) {
-            f32x4 xv[4], gv[4];
+        constexpr int PX = 8;  // pixels per trip: 16 sixteen-byte loads in flight per thread
+        for (; p + (PX - 1) * rows < p1; p += PX * rows) {
+            f32x4 xv[PX], gv[PX];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PX; ++k) {
                 const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
-                xv[k] = *reinterpret_cast<const f32x4*>(x + o);
-                gv[k] = *reinterpret_cast<const f32x4*>(dy + o);
+                xv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + o));
+                gv[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dy + o));
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PX; ++k) {
                 const size_t o = base + (size_t)(p + k * rows) * C + 4 * q;
                 const f32x4 xh = (xv[k] - mu) * rs;
                 f32x4 gg = gv[k];
